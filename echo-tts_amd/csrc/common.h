@@ -1,0 +1,177 @@
+// Shared device/host helpers for libechohip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define ECHO_OK 0
+#define ECHO_ERR 1
+
+// ---------------------------------------------------------------- numeric traits
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Num;
+template <> struct Num<bf16_t> {
+  static constexpr bool is_bf16 = true;
+  __device__ __forceinline__ static float ld(bf16_t v) { return bf2f(v); }
+  __device__ __forceinline__ static bf16_t st(float f) { return f2bf(f); }
+  __device__ __forceinline__ static float rnd(float f) { return bf2f(f2bf(f)); }
+};
+template <> struct Num<float> {
+  static constexpr bool is_bf16 = false;
+  __device__ __forceinline__ static float ld(float v) { return v; }
+  __device__ __forceinline__ static float st(float f) { return f; }
+  __device__ __forceinline__ static float rnd(float f) { return f; }
+};
+
+// 4 consecutive elements of T <-> 4 floats
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16_t> {
+  typedef uint2 raw;
+  __device__ __forceinline__ static void unpack(raw r, float* f) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+  __device__ __forceinline__ static raw pack(const float* f) {
+    raw r;
+    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    return r;
+  }
+};
+template <> struct Vec4<float> {
+  typedef float4 raw;
+  __device__ __forceinline__ static void unpack(raw r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+  __device__ __forceinline__ static raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[m][n] = epilogue( sum_{tap,k} A[m + tap_base + tap*tap_shift][k] * W[n][tap*K + k] )
+// A rows and W rows are K-contiguous ("NT").  See DESIGN.md "Kernels / gemm_nt".
+struct GemmArgs {
+  const void* A; const void* W; void* C; void* C2;
+  int M, N, K, Npad;            // K per tap (multiple of 128 bytes / sizeof(T)); Npad = rows of W (multiple of 128)
+  long lda, ldw, ldc;           // in elements
+  int taps, tap_base, tap_shift;
+  int nbatch, nbi;              // blockIdx.y = z -> (zo = z / nbi, zi = z % nbi)
+  long a_bo, a_bi, w_bo, w_bi, c_bo, c_bi;
+  float acc_scale;              // y = acc * acc_scale (1.0f = none)
+  const void* bias; long bias_bo, bias_bi; int vec_mod;   // per-column vectors are indexed n % vec_mod (0 = n)
+  float div;                    // != 0: y = rnd(y / div)
+  int act;                      // 0 none, 1 silu, 2 gelu(erf)
+  const void* colscale;         // y = rnd(y * colscale[n])
+  const void* res; long ldres, res_bo, res_bi;            // y = rnd(y + res[m][n])
+  const void* snake_alpha;      // C2[m][n] = rnd(snake(y, alpha[n]))
+  int store_main;               // write y to C
+  int swiglu;                   // W rows interleaved [16 x w1 | 16 x w3]; C has N/2 columns
+};
+void gemm_args_init(GemmArgs* g);
+template <typename T> hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+struct AttnSeg {
+  const bf16_t* K; long k_ld, k_row_stride, k_head_stride;
+  const bf16_t* Vt; long vt_ld, vt_row_stride, vt_head_stride;
+  const int* nkeys;             // [rows] number of leading keys that may be attended (device)
+  const float* bias; long bias_row_stride;  // optional additive bias (0 / -inf) per key, per row
+  int kv_mod;                   // kv batch index = kv_mod ? row % kv_mod : row
+};
+struct AttnArgs {
+  const bf16_t* Q; long q_ld, q_row_stride;
+  bf16_t* O; long o_ld, o_row_stride;
+  const bf16_t* G; long g_ld, g_row_stride;   // optional pre-sigmoid gate, same indexing as O
+  int S, H, rows;
+  int nseg; AttnSeg seg[4];
+  int causal;                   // only with nseg == 1 (encoder self-attention)
+  float scale;
+};
+hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- elementwise (elementwise.hip)
+enum NormMode { NORM_ADALN = 0, NORM_RMS_W = 1, NORM_AE_RMS = 2, NORM_LAYER = 3 };
+template <typename T>
+hipError_t launch_norm(int mode, const T* x, long ldx, T* y, long ldy, int rows, int D, float eps,
+                       const T* w0, const T* w1, hipStream_t st);
+// per-head RMSNorm(weight (H,HD)) + interleaved-pair RoPE on heads < rope_heads, in place, HD = 128
+template <typename T>
+hipError_t launch_headnorm_rope(T* x, long ldx, int rows, int S, int H, const T* w, float eps, int do_norm,
+                                int rope_heads, const float2* rope, int pos0, int pos_mul, hipStream_t st);
+// Vt[b][h][d][s] = V[b*S + s][h*HD + d]
+template <typename T>
+hipError_t launch_transpose_heads(const T* v, long ldv, T* vt, long vt_ld, long vt_b_stride, int B, int S, int H,
+                                  int HD, hipStream_t st);
+template <typename T>
+hipError_t launch_headnorm_rope_nt(T* x, long ldx, long t_stride, int nt, int rows, int S, int H, const T* w, long w_stride,
+                                   float eps, int do_norm, int rope_heads, const float2* rope, int pos0, int pos_mul,
+                                   hipStream_t st);
+template <typename T> hipError_t launch_embedding(const int* ids, const T* table, T* out, long ldo, int n, int D, hipStream_t st);
+template <typename T> hipError_t launch_silu(const T* x, T* y, long n, hipStream_t st);
+template <typename T> hipError_t launch_scale_inplace(T* x, long n, float s, hipStream_t st);
+template <typename T> hipError_t launch_scale_2d(T* x, long ld, int rows, int cols, float s, hipStream_t st);
+template <typename T> hipError_t launch_mod_finalize(T* mod, long rows, int D, hipStream_t st);
+template <typename T> hipError_t launch_convert_from_f32(const float* x, long ldx, T* y, long ldy, int rows, int cols, int cols_pad, hipStream_t st);
+template <typename T> hipError_t launch_convert_to_f32(const T* x, long ldx, float* y, long ldy, int rows, int cols, hipStream_t st);
+hipError_t launch_convert_any(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t st);
+// packed row copy with dtype conversion: dst[map(r)][c] = src[r][c]
+hipError_t launch_pack_rows(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld,
+                            int rows, int cols, int dst_row0, int swiglu_half /*-1 none, 0 w1, 1 w3*/, hipStream_t st);
+
+struct EulerArgs {
+  float* x;            // (B, S, L) fp32 state, updated in place
+  const void* v;       // model output, (R*B*S, ldv) of T, rows ordered [cond | uncond_text | uncond_speaker]
+  long ldv;
+  void* xin;           // (R*B*S, ld_xin) of T: next model input (all R copies), zero padded columns
+  long ld_xin;
+  int B, S, L, R;      // R = 3 (cfg) or 1;  R_next = rows to write into xin
+  int R_next;
+  float s_text, s_spk;
+  int rescale; float r_inv1mt, r_ratio, r_1mt;
+  float dt;            // t_next - t
+  float init_scale;    // != 0: x = x * init_scale first and no model step (used for truncation / initial cast)
+};
+template <typename T> hipError_t launch_euler(const EulerArgs& e, hipStream_t st);
+
+// fp32 softmax over rows of a score matrix with per-key bias and optional causal window
+hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch, int ncols, int ncols_pad,
+                              const float* bias, long bias_batch_stride, int heads_per_bias_row,
+                              int causal, int window, hipStream_t st);
+hipError_t launch_mask_to_bias(const uint8_t* mask, float* bias, long n, hipStream_t st);
+
+// ---------------------------------------------------------------- DAC helpers (dac.hip)
+// All take channels-last fp32 activations x[t][c]; S = time steps per batch item (causal padding restarts there).
+hipError_t launch_ae_rope(float* x, long ldx, int rows, int S, int H, int HD, const float* cache /*(pos,HD/2,2)*/, hipStream_t st);
+hipError_t launch_dwconv_ln(const float* x, long ldx, float* y, long ldy, int T, int S, int C, const float* w /*(C,7)*/,
+                            const float* b, const float* lnw, const float* lnb, float eps, hipStream_t st);
+hipError_t launch_conv_out_tanh(const float* x, long ldx, float* y, long T, int S, int C, int k, const float* w /*(k,C)*/,
+                                float bias, hipStream_t st);
+hipError_t launch_pca_prep(const float* lat, float* out, long ldo, long rows, int L, int Lpad, float scale, hipStream_t st);
+hipError_t launch_snake_f32(const float* x, long ldx, float* y, long ldy, long rows, int C, const float* alpha, hipStream_t st);

@@ -1,0 +1,153 @@
+// Small fp32 kernels of the Fish S1-DAC decode path that are not GEMM-shaped (channels-last
+// activations, x[t][c]).  The convolutions themselves run through gemm_nt (taps loop).
+#include "common.h"
+
+namespace {
+
+// autoencoder.py:815-826: interleaved pairs, cos/sin cache (pos, HD/2, 2) (bf16-rounded values, held as fp32)
+__global__ void ae_rope_kernel(float* __restrict__ x, long ldx, long rows, int S, int H, int HD, const float* __restrict__ cache) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = HD >> 1;
+  const long n = rows * H * half;
+  if (i >= n) return;
+  const long row = i / (H * half);
+  const int rem = (int)(i - row * (H * half));
+  const int h = rem / half, j = rem - h * half;
+  const int pos = (int)(row % S);
+  float* p = x + row * ldx + h * HD + 2 * j;
+  const float c = cache[((long)pos * half + j) * 2], s = cache[((long)pos * half + j) * 2 + 1];
+  const float a = p[0], b = p[1];
+  p[0] = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, s));
+  p[1] = __fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s));
+}
+
+// ConvNeXtBlock front half (autoencoder.py:362-364): causal depthwise conv k7 (+bias), then LayerNorm over C.
+// One wave per time step; lane owns float4 chunks lane + 64j.
+__global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int T, int S,
+                                                        int C, const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ lnw, const float* __restrict__ lnb, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int tl = (int)(t % S);  // position inside its own sequence (causal padding restarts per batch item)
+  constexpr int MAXC = 4;       // C <= 1024
+  const int nch = C >> 2;
+  float v[MAXC][4];
+  float s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      const float4 bb = *(const float4*)(b + ch * 4);
+      float acc[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int dt = k - 6;
+        if (tl + dt < 0) continue;
+        const float4 xv = *(const float4*)(x + (t + dt) * ldx + ch * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(ch * 4 + i) * 7 + k], xs[i], acc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[c][i] = acc[i]; s1 += acc[i]; }
+    }
+  }
+  const float mean = wave_sum(s1) / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mean; var += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(var) / (float)C + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      const float4 g = *(const float4*)(lnw + ch * 4), be = *(const float4*)(lnb + ch * 4);
+      float4 o;
+      o.x = (v[c][0] - mean) * rs * g.x + be.x;
+      o.y = (v[c][1] - mean) * rs * g.y + be.y;
+      o.z = (v[c][2] - mean) * rs * g.z + be.z;
+      o.w = (v[c][3] - mean) * rs * g.w + be.w;
+      *(float4*)(y + t * ldy + ch * 4) = o;
+    }
+  }
+}
+
+// Decoder tail (autoencoder.py:994): causal conv k, C -> 1, then tanh.  x already has the Snake applied.
+__global__ void conv_out_tanh_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long T, int S, int C, int k,
+                                     const float* __restrict__ w, float bias) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int tl = (int)(t % S);
+  float acc = bias;
+  for (int kk = 0; kk < k; ++kk) {
+    const int dt = kk - (k - 1);
+    if (tl + dt < 0) continue;
+    const float* xr = x + (t + dt) * ldx;
+    const float* wr = w + kk * C;
+    float part = 0.f;
+    for (int c = 0; c < C; c += 4) {
+      const float4 xv = *(const float4*)(xr + c), wv = *(const float4*)(wr + c);
+      part = fmaf(xv.x, wv.x, part); part = fmaf(xv.y, wv.y, part);
+      part = fmaf(xv.z, wv.z, part); part = fmaf(xv.w, wv.w, part);
+    }
+    acc += part;
+  }
+  y[t] = tanhf(acc);
+}
+
+// inference.py:228 front: out[r][l] = lat[r][l] / latent_scale, zero padded to Lpad columns
+__global__ void pca_prep_kernel(const float* __restrict__ lat, float* __restrict__ out, long ldo, long rows, int L, int Lpad, float scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Lpad) return;
+  const long r = i / Lpad;
+  const int l = (int)(i - r * Lpad);
+  out[r * ldo + l] = l < L ? lat[r * L + l] / scale : 0.0f;
+}
+
+// autoencoder.py:96-102
+__global__ void snake_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int C, const float* __restrict__ alpha) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  const float a = alpha[c], v = x[r * ldx + c];
+  const float sn = sinf(a * v);
+  y[r * ldy + c] = v + (1.0f / (a + 1e-9f)) * (sn * sn);
+}
+
+inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+hipError_t launch_ae_rope(float* x, long ldx, int rows, int S, int H, int HD, const float* cache, hipStream_t st) {
+  const long n = (long)rows * H * (HD / 2);
+  hipLaunchKernelGGL(ae_rope_kernel, grid1d(n), dim3(256), 0, st, x, ldx, (long)rows, S, H, HD, cache);
+  return hipGetLastError();
+}
+hipError_t launch_dwconv_ln(const float* x, long ldx, float* y, long ldy, int T, int S, int C, const float* w, const float* b,
+                            const float* lnw, const float* lnb, float eps, hipStream_t st) {
+  if (C % 4 || C > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dwconv_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, ldx, y, ldy, T, S, C, w, b, lnw, lnb, eps);
+  return hipGetLastError();
+}
+hipError_t launch_conv_out_tanh(const float* x, long ldx, float* y, long T, int S, int C, int k, const float* w, float bias,
+                                hipStream_t st) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv_out_tanh_kernel, grid1d(T), dim3(256), 0, st, x, ldx, y, T, S, C, k, w, bias);
+  return hipGetLastError();
+}
+hipError_t launch_pca_prep(const float* lat, float* out, long ldo, long rows, int L, int Lpad, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(pca_prep_kernel, grid1d(rows * Lpad), dim3(256), 0, st, lat, out, ldo, rows, L, Lpad, scale);
+  return hipGetLastError();
+}
+hipError_t launch_snake_f32(const float* x, long ldx, float* y, long ldy, long rows, int C, const float* alpha, hipStream_t st) {
+  hipLaunchKernelGGL(snake_kernel, grid1d(rows * C), dim3(256), 0, st, x, ldx, y, ldy, rows, C, alpha);
+  return hipGetLastError();
+}

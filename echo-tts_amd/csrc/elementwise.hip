@@ -1,0 +1,424 @@
+// HBM-bound row / elementwise kernels of the hot path (wave64 shuffles, 16-byte vector access).
+// Each kernel cites the reference expression whose rounding points it reproduces
+// (SURVEY.md §A.2): values are rounded to the activation type T exactly where eager PyTorch
+// materialises a tensor; for T = float `rnd` is the identity.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ 8-element chunks
+template <typename T> struct Chunk8;
+template <> struct Chunk8<bf16_t> {
+  __device__ __forceinline__ static void load(const bf16_t* p, float* f) {
+    const uint4 r = *(const uint4*)p;
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  __device__ __forceinline__ static void store(bf16_t* p, const float* f) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    *(uint4*)p = r;
+  }
+};
+template <> struct Chunk8<float> {
+  __device__ __forceinline__ static void load(const float* p, float* f) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+  __device__ __forceinline__ static void store(float* p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+};
+
+// ------------------------------------------------------------------ row norms
+// NORM_ADALN : model.py:76-83  y = T( (x * rsqrt(mean x^2 + eps)) * scale1p + shift ), scale1p = T(scale + 1)
+// NORM_RMS_W : model.py:99-104 y = T( (x * rsqrt(...)) * w )
+// NORM_AE_RMS: autoencoder.py:726-731 y = T( T(x * rsqrt(...)) * w )
+// NORM_LAYER : F.layer_norm (autoencoder.py:364)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) norm_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int rows,
+                                                   int D, float eps, const T* __restrict__ w0, const T* __restrict__ w1) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int MAXC = 8;  // up to 8 chunks of 8 per lane: D <= 4096
+  const int nch = D >> 3;
+  float v[MAXC][8];
+  float s1 = 0.f, s2 = 0.f;
+  const T* xr = x + (long)row * ldx;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      Chunk8<T>::load(xr + ch * 8, v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s2 += v[c][i] * v[c][i]; s1 += v[c][i]; }
+    }
+  }
+  s2 = wave_sum(s2);
+  float mean = 0.f, rs;
+  if (MODE == NORM_LAYER) {
+    s1 = wave_sum(s1);
+    mean = s1 / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; var += d * d; }
+      }
+    }
+    var = wave_sum(var) / (float)D;
+    rs = rsqrtf(var + eps);
+  } else {
+    rs = rsqrtf(s2 / (float)D + eps);
+  }
+  T* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float a[8], b[8], o[8];
+      Chunk8<T>::load(w0 + ch * 8, a);
+      if (MODE == NORM_ADALN || MODE == NORM_LAYER) Chunk8<T>::load(w1 + ch * 8, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (MODE == NORM_ADALN) o[i] = __fadd_rn(__fmul_rn(__fmul_rn(v[c][i], rs), a[i]), b[i]);
+        else if (MODE == NORM_RMS_W) o[i] = __fmul_rn(__fmul_rn(v[c][i], rs), a[i]);
+        else if (MODE == NORM_AE_RMS) o[i] = __fmul_rn(Num<T>::rnd(__fmul_rn(v[c][i], rs)), a[i]);
+        else o[i] = __fadd_rn(__fmul_rn(__fmul_rn(v[c][i] - mean, rs), a[i]), b[i]);
+      }
+      Chunk8<T>::store(yr + ch * 8, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ per-head RMSNorm + RoPE (HD = 128)
+// model.py:221-232 (q_norm/k_norm then _apply_rotary_half), model.py:138-142 (encoders: all heads),
+// model.py:289-291 (latent keys, positions 4*i).  One wave per (token, head); lane j owns the
+// interleaved pair (x[2j], x[2j+1]).  Rounds to T after the norm and again after the rotation.
+template <typename T>
+__global__ void __launch_bounds__(256) headnorm_rope_kernel(T* __restrict__ x, long ldx, long t_stride, int rows, int S, int H,
+                                                            const T* __restrict__ w, long w_stride, float eps, int do_norm,
+                                                            int rope_heads, const float2* __restrict__ rope, int pos0,
+                                                            int pos_mul) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long)rows * H) return;
+  const int row = (int)(item / H), h = (int)(item - (long)row * H);
+  const int tsel = blockIdx.y;
+  T* p = x + tsel * t_stride + (long)row * ldx + h * 128 + 2 * lane;
+  float a = Num<T>::ld(p[0]), b = Num<T>::ld(p[1]);
+  if (do_norm) {
+    const float ss = wave_sum(a * a + b * b);
+    const float rs = rsqrtf(ss / 128.0f + eps);
+    const T* wp = w + tsel * w_stride + h * 128 + 2 * lane;
+    a = Num<T>::rnd(__fmul_rn(__fmul_rn(a, rs), Num<T>::ld(wp[0])));
+    b = Num<T>::rnd(__fmul_rn(__fmul_rn(b, rs), Num<T>::ld(wp[1])));
+  }
+  if (h < rope_heads) {
+    const int pos = pos0 + (row % S) * pos_mul;
+    const float2 cs = rope[(long)pos * 64 + lane];
+    const float re = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(b, cs.y));
+    const float im = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(b, cs.x));
+    a = re; b = im;
+  }
+  p[0] = Num<T>::st(a);
+  p[1] = Num<T>::st(b);
+}
+
+// ------------------------------------------------------------------ V -> Vᵀ per head
+// Vt[b][h][d][s] = V[b*S + s][h*HD + d]; a workgroup moves a 64(s) x HD tile through LDS.  Keys
+// s >= S inside the last tile are written as zeros so that the padding of Vᵀ stays finite.
+template <typename T, int HD>
+__global__ void __launch_bounds__(256) transpose_heads_kernel(const T* __restrict__ v, long ldv, T* __restrict__ vt, long vt_ld,
+                                                              long vt_b_stride, int S, int H) {
+  __shared__ T tile[64][HD + 2];
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < 64 * HD; i += 256) {
+    const int r = i / HD, d = i - r * HD;
+    const int s = s0 + r;
+    tile[r][d] = s < S ? v[((long)b * S + s) * ldv + h * HD + d] : (T)0;
+  }
+  __syncthreads();
+  T* out = vt + (long)b * vt_b_stride + (long)h * HD * vt_ld;
+  for (int i = threadIdx.x; i < 64 * HD; i += 256) {
+    const int d = i >> 6, r = i & 63;
+    out[(long)d * vt_ld + s0 + r] = tile[r][d];
+  }
+}
+
+template <typename T>
+__global__ void embedding_kernel(const int* __restrict__ ids, const T* __restrict__ table, T* __restrict__ out, long ldo, int n, int D) {
+  const int row = blockIdx.x;
+  if (row >= n) return;
+  const T* src = table + (long)ids[row] * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(long)row * ldo + c] = src[c];
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = Num<T>::st(silu_f(Num<T>::ld(x[i])));
+}
+
+template <typename T>
+__global__ void scale2d_kernel(T* __restrict__ x, long ld, int rows, int cols, float s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const long r = i / cols, c = i - r * cols;
+  T* p = x + r * ld + c;
+  *p = Num<T>::st(__fmul_rn(Num<T>::ld(*p), s));
+}
+
+// mod table rows = [shift | scale | gate] x D: scale -> T(scale + 1) (model.py:79), gate -> T(tanh(gate)) (model.py:81)
+template <typename T>
+__global__ void mod_finalize_kernel(T* __restrict__ mod, long rows, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 3 * D) return;
+  const int part = (int)((i / D) % 3);
+  if (part == 0) return;
+  const float v = Num<T>::ld(mod[i]);
+  mod[i] = Num<T>::st(part == 1 ? __fadd_rn(v, 1.0f) : tanhf(v));
+}
+
+template <typename T>
+__global__ void from_f32_kernel(const float* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int rows, int cols, int cols_pad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols_pad) return;
+  const long r = i / cols_pad;
+  const int c = (int)(i - r * cols_pad);
+  y[r * ldy + c] = c < cols ? Num<T>::st(x[r * ldx + c]) : (T)0;
+}
+
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int rows, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  y[r * ldy + c] = Num<T>::ld(x[r * ldx + c]);
+}
+
+__device__ __forceinline__ float load_any(const void* p, int dt, long i) {
+  return dt == 0 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void store_any(void* p, int dt, long i, float v) {
+  if (dt == 0) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+
+// dst[dst_row0 + map(r)][c] = src[r][c] with dtype conversion (0 = f32, 1 = bf16).
+// swiglu_half h in {0,1}: source row j goes to packed row (j/16)*32 + h*16 + j%16  (gemm.hip SWIGLU layout).
+__global__ void pack_rows_kernel(const void* __restrict__ src, int sdt, long sld, void* __restrict__ dst, int ddt, long dld,
+                                 int rows, int cols, int dst_row0, int swiglu_half) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  long dr = r;
+  if (swiglu_half >= 0) dr = (r >> 4) * 32 + swiglu_half * 16 + (r & 15);
+  store_any(dst, ddt, (dst_row0 + dr) * dld + c, load_any(src, sdt, r * sld + c));
+}
+
+// ------------------------------------------------------------------ CFG combine + rescale + Euler (inference.py:487-515)
+template <typename T>
+__global__ void euler_kernel(const EulerArgs e) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)e.B * e.S * e.L;
+  if (i >= n) return;
+  const long tok = i / e.L;
+  const int l = (int)(i - tok * e.L);
+  float x = e.x[i];
+  if (e.init_scale != 0.0f) {
+    if (e.init_scale != 1.0f) x = __fmul_rn(x, e.init_scale);
+  } else {
+    const T* v = (const T*)e.v;
+    const long bs = (long)e.B * e.S;
+    float vp = Num<T>::ld(v[tok * e.ldv + l]);
+    if (e.R == 3) {
+      const float vut = Num<T>::ld(v[(bs + tok) * e.ldv + l]);
+      const float vus = Num<T>::ld(v[(2 * bs + tok) * e.ldv + l]);
+      const float a = __fmul_rn(e.s_text, __fsub_rn(vp, vut));
+      const float b = __fmul_rn(e.s_spk, __fsub_rn(vp, vus));
+      vp = __fadd_rn(__fadd_rn(vp, a), b);
+    }
+    if (e.rescale) {
+      float t = __fadd_rn(__fmul_rn(e.r_1mt, vp), x);
+      t = __fsub_rn(__fmul_rn(e.r_ratio, t), x);
+      vp = __fmul_rn(e.r_inv1mt, t);
+    }
+    x = __fadd_rn(x, __fmul_rn(vp, e.dt));
+  }
+  e.x[i] = x;
+  T* xin = (T*)e.xin;
+  const long bs = (long)e.B * e.S;
+  for (int r = 0; r < e.R_next; ++r) xin[(r * bs + tok) * e.ld_xin + l] = Num<T>::st(x);
+}
+
+// ------------------------------------------------------------------ fp32 softmax with key bias / causal window
+__global__ void __launch_bounds__(256) softmax_f32_kernel(float* __restrict__ s, long ld, int rows_per_batch, long total_rows, int ncols,
+                                                          int ncols_pad, const float* __restrict__ bias, long bias_batch_stride,
+                                                          int heads_per_bias_row, int causal, int window) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const long batch = row / rows_per_batch;
+  const int qi = (int)(row - batch * rows_per_batch);
+  float* p = s + row * ld;
+  const float* bp = bias ? bias + (batch / heads_per_bias_row) * bias_batch_stride : nullptr;
+  float mx = -INFINITY;
+  for (int c = lane; c < ncols; c += 64) {
+    float v = p[c];
+    if (bp) v += bp[c];
+    if (causal && (c > qi || (window > 0 && c < qi - window + 1))) v = -INFINITY;
+    p[c] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < ncols; c += 64) {
+    const float v = expf(p[c] - mx);
+    p[c] = v;
+    sum += v;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < ncols_pad; c += 64) p[c] = c < ncols ? p[c] * inv : 0.0f;
+}
+
+__global__ void mask_to_bias_kernel(const uint8_t* __restrict__ m, float* __restrict__ b, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = m[i] ? 0.0f : -INFINITY;
+}
+
+__global__ void convert_any_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst, int ddt, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) store_any(dst, ddt, i, load_any(src, sdt, i));
+}
+
+inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_norm(int mode, const T* x, long ldx, T* y, long ldy, int rows, int D, float eps, const T* w0, const T* w1,
+                       hipStream_t st) {
+  if (D % 8 || D > 4096 || rows <= 0) return hipErrorInvalidValue;
+  dim3 grid((rows + 3) / 4);
+  switch (mode) {
+    case NORM_ADALN: hipLaunchKernelGGL((norm_kernel<T, NORM_ADALN>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;
+    case NORM_RMS_W: hipLaunchKernelGGL((norm_kernel<T, NORM_RMS_W>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;
+    case NORM_AE_RMS: hipLaunchKernelGGL((norm_kernel<T, NORM_AE_RMS>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;
+    case NORM_LAYER: hipLaunchKernelGGL((norm_kernel<T, NORM_LAYER>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// x points at tensor 0; nt tensors (q, k) spaced t_stride elements apart share the launch.
+template <typename T>
+hipError_t launch_headnorm_rope_nt(T* x, long ldx, long t_stride, int nt, int rows, int S, int H, const T* w, long w_stride,
+                                   float eps, int do_norm, int rope_heads, const float2* rope, int pos0, int pos_mul,
+                                   hipStream_t st) {
+  const long items = (long)rows * H;
+  dim3 grid((unsigned)((items + 3) / 4), nt);
+  hipLaunchKernelGGL(headnorm_rope_kernel<T>, grid, dim3(256), 0, st, x, ldx, t_stride, rows, S, H, w, w_stride, eps, do_norm,
+                     rope_heads, rope, pos0, pos_mul);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_headnorm_rope(T* x, long ldx, int rows, int S, int H, const T* w, float eps, int do_norm, int rope_heads,
+                                const float2* rope, int pos0, int pos_mul, hipStream_t st) {
+  return launch_headnorm_rope_nt<T>(x, ldx, 0, 1, rows, S, H, w, 0, eps, do_norm, rope_heads, rope, pos0, pos_mul, st);
+}
+
+template <typename T>
+hipError_t launch_transpose_heads(const T* v, long ldv, T* vt, long vt_ld, long vt_b_stride, int B, int S, int H, int HD,
+                                  hipStream_t st) {
+  dim3 grid((S + 63) / 64, H, B);
+  if (vt_ld < (long)grid.x * 64) return hipErrorInvalidValue;
+  if (HD == 128) hipLaunchKernelGGL((transpose_heads_kernel<T, 128>), grid, dim3(256), 0, st, v, ldv, vt, vt_ld, vt_b_stride, S, H);
+  else if (HD == 64) hipLaunchKernelGGL((transpose_heads_kernel<T, 64>), grid, dim3(256), 0, st, v, ldv, vt, vt_ld, vt_b_stride, S, H);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_embedding(const int* ids, const T* table, T* out, long ldo, int n, int D, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_kernel<T>, dim3(n), dim3(256), 0, st, ids, table, out, ldo, n, D);
+  return hipGetLastError();
+}
+template <typename T> hipError_t launch_silu(const T* x, T* y, long n, hipStream_t st) {
+  hipLaunchKernelGGL(silu_kernel<T>, grid1d(n), dim3(256), 0, st, x, y, n);
+  return hipGetLastError();
+}
+template <typename T> hipError_t launch_scale_2d(T* x, long ld, int rows, int cols, float s, hipStream_t st) {
+  hipLaunchKernelGGL(scale2d_kernel<T>, grid1d((long)rows * cols), dim3(256), 0, st, x, ld, rows, cols, s);
+  return hipGetLastError();
+}
+template <typename T> hipError_t launch_scale_inplace(T* x, long n, float s, hipStream_t st) {
+  return launch_scale_2d<T>(x, n, 1, (int)n, s, st);
+}
+template <typename T> hipError_t launch_mod_finalize(T* mod, long rows, int D, hipStream_t st) {
+  hipLaunchKernelGGL(mod_finalize_kernel<T>, grid1d(rows * 3 * D), dim3(256), 0, st, mod, rows, D);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_convert_from_f32(const float* x, long ldx, T* y, long ldy, int rows, int cols, int cols_pad, hipStream_t st) {
+  hipLaunchKernelGGL(from_f32_kernel<T>, grid1d((long)rows * cols_pad), dim3(256), 0, st, x, ldx, y, ldy, rows, cols, cols_pad);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_convert_to_f32(const T* x, long ldx, float* y, long ldy, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(to_f32_kernel<T>, grid1d((long)rows * cols), dim3(256), 0, st, x, ldx, y, ldy, rows, cols);
+  return hipGetLastError();
+}
+hipError_t launch_convert_any(const void* src, int sdt, void* dst, int ddt, long n, hipStream_t st) {
+  hipLaunchKernelGGL(convert_any_kernel, grid1d(n), dim3(256), 0, st, src, sdt, dst, ddt, n);
+  return hipGetLastError();
+}
+hipError_t launch_pack_rows(const void* src, int sdt, long sld, void* dst, int ddt, long dld, int rows, int cols, int dst_row0,
+                            int swiglu_half, hipStream_t st) {
+  hipLaunchKernelGGL(pack_rows_kernel, grid1d((long)rows * cols), dim3(256), 0, st, src, sdt, sld, dst, ddt, dld, rows, cols,
+                     dst_row0, swiglu_half);
+  return hipGetLastError();
+}
+template <typename T> hipError_t launch_euler(const EulerArgs& e, hipStream_t st) {
+  hipLaunchKernelGGL(euler_kernel<T>, grid1d((long)e.B * e.S * e.L), dim3(256), 0, st, e);
+  return hipGetLastError();
+}
+hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch, int ncols, int ncols_pad, const float* bias,
+                              long bias_batch_stride, int heads_per_bias_row, int causal, int window, hipStream_t st) {
+  const long total = (long)rows_per_batch * nbatch;
+  hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, s, ld, rows_per_batch, total, ncols,
+                     ncols_pad, bias, bias_batch_stride, heads_per_bias_row < 1 ? 1 : heads_per_bias_row, causal, window);
+  return hipGetLastError();
+}
+hipError_t launch_mask_to_bias(const uint8_t* mask, float* bias, long n, hipStream_t st) {
+  hipLaunchKernelGGL(mask_to_bias_kernel, grid1d(n), dim3(256), 0, st, mask, bias, n);
+  return hipGetLastError();
+}
+
+#define INST(T)                                                                                                              \
+  template hipError_t launch_norm<T>(int, const T*, long, T*, long, int, int, float, const T*, const T*, hipStream_t);        \
+  template hipError_t launch_headnorm_rope_nt<T>(T*, long, long, int, int, int, int, const T*, long, float, int, int,         \
+                                                 const float2*, int, int, hipStream_t);                                       \
+  template hipError_t launch_headnorm_rope<T>(T*, long, int, int, int, const T*, float, int, int, const float2*, int, int,    \
+                                              hipStream_t);                                                                   \
+  template hipError_t launch_transpose_heads<T>(const T*, long, T*, long, long, int, int, int, int, hipStream_t);            \
+  template hipError_t launch_embedding<T>(const int*, const T*, T*, long, int, int, hipStream_t);                            \
+  template hipError_t launch_silu<T>(const T*, T*, long, hipStream_t);                                                       \
+  template hipError_t launch_scale_2d<T>(T*, long, int, int, float, hipStream_t);                                            \
+  template hipError_t launch_scale_inplace<T>(T*, long, float, hipStream_t);                                                 \
+  template hipError_t launch_mod_finalize<T>(T*, long, int, hipStream_t);                                                    \
+  template hipError_t launch_convert_from_f32<T>(const float*, long, T*, long, int, int, int, hipStream_t);                  \
+  template hipError_t launch_convert_to_f32<T>(const T*, long, float*, long, int, int, hipStream_t);                         \
+  template hipError_t launch_euler<T>(const EulerArgs&, hipStream_t);
+INST(bf16_t)
+INST(float)

@@ -1,0 +1,1348 @@
+// Host-side engine of libechohip: weight packing, KV caches, the EchoDiT forward, the Euler/CFG
+// sampler loop and the Fish S1-DAC decode, as static schedules of the HIP kernels in this directory.
+// Everything is enqueued on the caller's stream from C++ (no Python in the step loop).
+#include "common.h"
+#include "../../include/echo_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    bytes = (size_t)rup((long)bytes, 4096);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    cap = bytes;
+    return hipMemset(p, 0, bytes);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename U> U* as() const { return (U*)p; }
+};
+
+struct RawTensor {
+  void* d = nullptr;
+  int dtype = 0;
+  std::vector<int64_t> shape;
+  long numel = 0;
+};
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int code = ECHO_F32; };
+template <> struct DT<bf16_t> { static constexpr int code = ECHO_BF16; };
+
+// combined key bias for the fp32 (parity-mode) attention: columns are the concatenated segments
+__global__ void build_bias_kernel(float* __restrict__ dst, long ld, int rows, int nseg, const int* __restrict__ seg_off,
+                                  const int* __restrict__ seg_w, const int* __restrict__ nkeys /*[4][maxrows]*/, int maxrows,
+                                  const float* b2, long b2_stride, int b2_mod, const float* b3, long b3_stride, int b3_mod, int ncols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * ncols) return;
+  const int r = (int)(i / ncols), c = (int)(i - (long)r * ncols);
+  float v = -INFINITY;
+  for (int s = 0; s < nseg; ++s) {
+    const int k = c - seg_off[s];
+    if (k >= 0 && k < seg_w[s]) {
+      if (k < nkeys[s * maxrows + r]) {
+        v = 0.0f;
+        if (s == 2 && b2) v = b2[(long)(b2_mod ? r % b2_mod : r) * b2_stride + k];
+        if (s == 3 && b3) v = b3[(long)(b3_mod ? r % b3_mod : r) * b3_stride + k];
+      }
+      break;
+    }
+  }
+  dst[(long)r * ld + c] = v;
+}
+
+// y = T(T(o) * T(sigmoid(g)))  (model.py:157,264) for the unfused fp32 path
+template <typename T>
+__global__ void gate_mul_kernel(T* __restrict__ o, long ldo, const T* __restrict__ g, long ldg, long rows, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  const float ov = Num<T>::ld(o[r * ldo + c]);
+  const float sg = Num<T>::rnd(sigmoid_f(Num<T>::ld(g[r * ldg + c])));
+  o[r * ldo + c] = Num<T>::st(ov * sg);
+}
+
+struct EngineBase {
+  echo_config cfg{};
+  int device = 0;
+  std::string err;
+  std::map<std::string, RawTensor> raw;
+  bool dit_ready = false, dac_ready = false;
+  bool profiling = false;
+  echo_profile prof{};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
+  size_t gemm_events_used = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  virtual ~EngineBase() {
+    for (auto& kv : raw) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (auto& e : gemm_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+  }
+  int fail(const std::string& m) { err = m; return ECHO_ERR; }
+  int fail(hipError_t e, const char* what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return ECHO_ERR;
+  }
+  virtual int finalize_dit(hipStream_t st) = 0;
+  virtual int finalize_dac(hipStream_t st) = 0;
+  virtual int set_rope(const void* t, int npos) = 0;
+  virtual int set_ae_rope(const void* t, int npos) = 0;
+  virtual int encode_text(const int32_t* ids, const float* bias, const int32_t* nk, int B, int Tt, hipStream_t st) = 0;
+  virtual int encode_speaker(const void* lat, const float* bias, const int32_t* nk, int B, int Ts, hipStream_t st) = 0;
+  virtual int encode_latent(const void* lat, int B, int n, long row_stride, hipStream_t st) = 0;
+  virtual int scale_speaker_kv(float s, int max_layers, hipStream_t st) = 0;
+  virtual int dit_forward(const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
+                          const int32_t* ton, const int32_t* son, float* v, hipStream_t st) = 0;
+  virtual int sample_euler(const echo_sampler_params* p, const float* x0, float* out, hipStream_t st) = 0;
+  virtual int dac_decode(const float* lat, int T, float scale, float* wav, hipStream_t st) = 0;
+  virtual int dac_decode_zq(const float* z, int T, float* wav, hipStream_t st) = 0;
+  virtual int set_pca(const float* w, const float* mean, int on_device, hipStream_t st) = 0;
+  virtual int debug_get_kv(int which, int layer, float* k, float* v, int* B, int* T) = 0;
+};
+
+#define CK(x)                                            \
+  do {                                                   \
+    hipError_t e__ = (x);                                \
+    if (e__ != hipSuccess) return this->fail(e__, #x);   \
+  } while (0)
+#define CKI(x)                          \
+  do {                                  \
+    int r__ = (x);                      \
+    if (r__ != ECHO_OK) return r__;     \
+  } while (0)
+
+template <typename T>
+struct Engine : EngineBase {
+  static constexpr int KE = 128 / (int)sizeof(T);   // GEMM K granularity in elements
+  std::vector<void*> owned;                           // packed weights
+
+  ~Engine() override {
+    for (void* p : owned) (void)hipFree(p);
+    for (DevBuf* b : all_bufs()) b->release();
+  }
+
+  // ------------------------------------------------------------------ weights
+  struct EncW {
+    int d = 0, H = 0, F = 0, L = 0;
+    std::vector<T*> wqkvg, wo, w13, w2, an, mn;
+    T* qkn = nullptr;   // [L][2][d]
+    T* in_w = nullptr; T* in_b = nullptr; int in_k = 0;
+    T* out_norm = nullptr;
+    T* kv_w = nullptr;  // [Ldit*2*D][d]
+  };
+  EncW tenc, senc, lenc;
+  T* text_emb = nullptr;
+  T *cond0 = nullptr, *cond2 = nullptr, *cond4 = nullptr, *in_w = nullptr, *in_b = nullptr;
+  std::vector<T*> wqkvg, wo, w13, w2;
+  T *qkn = nullptr, *mod_down = nullptr, *mod_up = nullptr, *mod_up_b = nullptr, *out_norm = nullptr, *out_w = nullptr,
+    *out_b = nullptr;
+  int rank_pad = 0, lat_pad = 0;
+  const float2* rope = nullptr; int rope_npos = 0;
+  const float* ae_rope = nullptr; int ae_rope_npos = 0;
+
+  // ------------------------------------------------------------------ caches and workspaces
+  DevBuf b_kv_text, b_vt_text, b_kv_spk, b_vt_spk, b_kv_lat, b_vt_lat, b_nkeys, b_bias_text, b_bias_spk;
+  DevBuf b_xin, b_x, b_xn, b_qkvg, b_vt_self, b_attn, b_h, b_vout, b_scores, b_biasrows, b_segmeta;
+  DevBuf b_mod, b_c1, b_c2, b_cond, b_sc, b_dn, b_xstate, b_vf32;
+  DevBuf b_ex, b_exn, b_eqkvg, b_evt, b_eattn, b_eh, b_ein, b_enk;
+  DevBuf b_dacA, b_dacB, b_dacC, b_dq, b_dscore, b_dvt, b_dmisc;
+  std::vector<DevBuf*> all_bufs() {
+    return {&b_kv_text, &b_vt_text, &b_kv_spk, &b_vt_spk, &b_kv_lat, &b_vt_lat, &b_nkeys, &b_bias_text, &b_bias_spk,
+            &b_xin, &b_x, &b_xn, &b_qkvg, &b_vt_self, &b_attn, &b_h, &b_vout, &b_scores, &b_biasrows, &b_segmeta,
+            &b_mod, &b_c1, &b_c2, &b_cond, &b_sc, &b_dn, &b_xstate, &b_vf32,
+            &b_ex, &b_exn, &b_eqkvg, &b_evt, &b_eattn, &b_eh, &b_ein, &b_enk,
+            &b_dacA, &b_dacB, &b_dacC, &b_dq, &b_dscore, &b_dvt, &b_dmisc};
+  }
+  // text / speaker / latent cache geometry
+  int kvB = 0;
+  int text_T = 0, text_pad = 0, text_vld = 0; std::vector<int> text_nk; bool text_has_bias = false; long text_bias_ld = 0;
+  int spk_T = 0, spk_pad = 0, spk_vld = 0; std::vector<int> spk_nk; bool spk_has_bias = false; long spk_bias_ld = 0;
+  int lat_T = 0, lat_pad_rows = 0, lat_vld = 0, latB = 0;
+  static constexpr int MAXROWS = 96;
+
+  // ------------------------------------------------------------------ helpers
+  hipError_t alloc_zero(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    owned.push_back(*p);
+    return hipMemset(*p, 0, bytes);
+  }
+  int walloc(T** p, long rows, long cols) {
+    CK(alloc_zero((void**)p, (size_t)rows * cols * sizeof(T)));
+    return ECHO_OK;
+  }
+  const RawTensor* find(const std::string& n) {
+    auto it = raw.find(n);
+    return it == raw.end() ? nullptr : &it->second;
+  }
+  // copy raw (rows, cols) tensor into dst rows starting at dst_row0
+  int pack(const std::string& name, T* dst, long dst_ld, int dst_row0, int rows, int cols, hipStream_t st, int swiglu_half = -1) {
+    const RawTensor* r = find(name);
+    if (!r) return fail("missing tensor: " + name);
+    if (r->numel != (long)rows * cols) return fail("shape mismatch for " + name);
+    CK(launch_pack_rows(r->d, r->dtype, cols, dst, DT<T>::code, dst_ld, rows, cols, dst_row0, swiglu_half, st));
+    return ECHO_OK;
+  }
+  int pack_vec(const std::string& name, T* dst, long n, hipStream_t st) { return pack(name, dst, n, 0, 1, (int)n, st); }
+
+  GemmArgs G(const T* A, long lda, const T* W, long ldw, T* C, long ldc, int M, int N, int K) {
+    GemmArgs g;
+    gemm_args_init(&g);
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.Npad = (int)rup(N, 128);
+    return g;
+  }
+  int run(const GemmArgs& g, hipStream_t st) {
+    if (profiling) {
+      if (gemm_events_used == gemm_events.size()) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        gemm_events.emplace_back(a, b);
+      }
+      auto& e = gemm_events[gemm_events_used++];
+      CK(hipEventRecord(e.first, st));
+      CK(launch_gemm_nt<T>(g, st));
+      CK(hipEventRecord(e.second, st));
+      return ECHO_OK;
+    }
+    CK(launch_gemm_nt<T>(g, st));
+    return ECHO_OK;
+  }
+
+  // ------------------------------------------------------------------ finalize: pack EchoDiT (SURVEY.md §A.5 names)
+  int pack_encoder(const std::string& pre, EncW& e, int d, int H, int F, int L, hipStream_t st) {
+    e.d = d; e.H = H; e.F = F; e.L = L;
+    if (d % KE || F % 64 || d / H != 128) return fail("unsupported encoder sizes");
+    CKI(walloc(&e.qkn, (long)L * 2, d));
+    for (int i = 0; i < L; ++i) {
+      const std::string p = pre + ".blocks." + std::to_string(i);
+      T *a, *b, *c, *dd, *n1, *n2;
+      CKI(walloc(&a, rup(4 * d, 128), d));
+      const char* names[4] = {"wq", "wk", "wv", "gate"};
+      for (int j = 0; j < 4; ++j) CKI(pack(p + ".attention." + names[j] + ".weight", a, d, j * d, d, d, st));
+      CKI(walloc(&b, rup(d, 128), d));
+      CKI(pack(p + ".attention.wo.weight", b, d, 0, d, d, st));
+      CKI(walloc(&c, rup(2 * F, 128), d));
+      CKI(pack(p + ".mlp.w1.weight", c, d, 0, F, d, st, 0));
+      CKI(pack(p + ".mlp.w3.weight", c, d, 0, F, d, st, 1));
+      CKI(walloc(&dd, rup(d, 128), F));
+      CKI(pack(p + ".mlp.w2.weight", dd, F, 0, d, F, st));
+      CKI(walloc(&n1, 1, d)); CKI(pack_vec(p + ".attention_norm.weight", n1, d, st));
+      CKI(walloc(&n2, 1, d)); CKI(pack_vec(p + ".mlp_norm.weight", n2, d, st));
+      CKI(pack_vec(p + ".attention.q_norm.weight", e.qkn + (long)i * 2 * d, d, st));
+      CKI(pack_vec(p + ".attention.k_norm.weight", e.qkn + (long)i * 2 * d + d, d, st));
+      e.wqkvg.push_back(a); e.wo.push_back(b); e.w13.push_back(c); e.w2.push_back(dd); e.an.push_back(n1); e.mn.push_back(n2);
+    }
+    return ECHO_OK;
+  }
+  int pack_kv_proj(const std::string& src, EncW& e, hipStream_t st) {
+    const int D = cfg.model_size, L = cfg.num_layers;
+    CKI(walloc(&e.kv_w, (long)L * 2 * D, e.d));
+    for (int l = 0; l < L; ++l) {
+      const std::string p = "blocks." + std::to_string(l) + ".attention.";
+      CKI(pack(p + "wk_" + src + ".weight", e.kv_w, e.d, l * 2 * D, D, e.d, st));
+      CKI(pack(p + "wv_" + src + ".weight", e.kv_w, e.d, l * 2 * D + D, D, e.d, st));
+    }
+    return ECHO_OK;
+  }
+  int pack_patch_in(const std::string& pre, EncW& e, hipStream_t st) {
+    e.in_k = cfg.latent_size * cfg.speaker_patch_size;
+    if (e.in_k % KE) return fail("latent_size * patch must be a multiple of the GEMM K step");
+    CKI(walloc(&e.in_w, rup(e.d, 128), e.in_k));
+    CKI(pack(pre + ".in_proj.weight", e.in_w, e.in_k, 0, e.d, e.in_k, st));
+    CKI(walloc(&e.in_b, 1, e.d));
+    CKI(pack_vec(pre + ".in_proj.bias", e.in_b, e.d, st));
+    return ECHO_OK;
+  }
+
+  int finalize_dit(hipStream_t st) override {
+    const int D = cfg.model_size, L = cfg.num_layers, H = cfg.num_heads, F = cfg.intermediate_size, E = cfg.timestep_embed_size;
+    const int R = cfg.adaln_rank;
+    if (D / H != 128 || D % 128 || F % 64 || E % KE || R % KE || D % KE) return fail("unsupported EchoDiT sizes (head_dim must be 128)");
+    if (L * 2 > MAXROWS * 8) return fail("too many layers");
+    lat_pad = (int)rup(cfg.latent_size, KE);
+    // encoders
+    CKI(walloc(&text_emb, cfg.text_vocab_size, cfg.text_model_size));
+    CKI(pack("text_encoder.text_embedding.weight", text_emb, cfg.text_model_size, 0, cfg.text_vocab_size, cfg.text_model_size, st));
+    CKI(pack_encoder("text_encoder", tenc, cfg.text_model_size, cfg.text_num_heads, cfg.text_intermediate_size, cfg.text_num_layers, st));
+    CKI(pack_encoder("speaker_encoder", senc, cfg.speaker_model_size, cfg.speaker_num_heads, cfg.speaker_intermediate_size, cfg.speaker_num_layers, st));
+    CKI(pack_patch_in("speaker_encoder", senc, st));
+    CKI(walloc(&tenc.out_norm, 1, tenc.d)); CKI(pack_vec("text_norm.weight", tenc.out_norm, tenc.d, st));
+    CKI(walloc(&senc.out_norm, 1, senc.d)); CKI(pack_vec("speaker_norm.weight", senc.out_norm, senc.d, st));
+    CKI(pack_kv_proj("text", tenc, st));
+    CKI(pack_kv_proj("speaker", senc, st));
+    if (cfg.has_latent_encoder) {
+      CKI(pack_encoder("latent_encoder", lenc, cfg.speaker_model_size, cfg.speaker_num_heads, cfg.speaker_intermediate_size, cfg.speaker_num_layers, st));
+      CKI(pack_patch_in("latent_encoder", lenc, st));
+      CKI(walloc(&lenc.out_norm, 1, lenc.d)); CKI(pack_vec("latent_norm.weight", lenc.out_norm, lenc.d, st));
+      CKI(pack_kv_proj("latent", lenc, st));
+    }
+    // conditioning
+    CKI(walloc(&cond0, D, E)); CKI(pack("cond_module.0.weight", cond0, E, 0, D, E, st));
+    CKI(walloc(&cond2, D, D)); CKI(pack("cond_module.2.weight", cond2, D, 0, D, D, st));
+    CKI(walloc(&cond4, 3L * D, D)); CKI(pack("cond_module.4.weight", cond4, D, 0, 3 * D, D, st));
+    CKI(walloc(&in_w, D, lat_pad)); CKI(pack("in_proj.weight", in_w, lat_pad, 0, D, cfg.latent_size, st));
+    CKI(walloc(&in_b, 1, D)); CKI(pack_vec("in_proj.bias", in_b, D, st));
+    // blocks
+    CKI(walloc(&qkn, (long)L * 2, D));
+    rank_pad = (int)rup(R, 128);
+    CKI(walloc(&mod_down, (long)L * 2 * 3 * rank_pad, D));
+    CKI(walloc(&mod_up, (long)L * 2 * 3 * D, R));
+    CKI(walloc(&mod_up_b, (long)L * 2 * 3, D));
+    const char* adn[2] = {"attention_adaln", "mlp_adaln"};
+    const char* parts[3] = {"shift", "scale", "gate"};
+    for (int l = 0; l < L; ++l) {
+      const std::string p = "blocks." + std::to_string(l);
+      T *a, *b, *c, *dd;
+      CKI(walloc(&a, 4L * D, D));
+      const char* names[4] = {"wq", "wk", "wv", "gate"};
+      for (int j = 0; j < 4; ++j) CKI(pack(p + ".attention." + names[j] + ".weight", a, D, j * D, D, D, st));
+      CKI(walloc(&b, D, D)); CKI(pack(p + ".attention.wo.weight", b, D, 0, D, D, st));
+      CKI(walloc(&c, rup(2 * F, 128), D));
+      CKI(pack(p + ".mlp.w1.weight", c, D, 0, F, D, st, 0));
+      CKI(pack(p + ".mlp.w3.weight", c, D, 0, F, D, st, 1));
+      CKI(walloc(&dd, D, F)); CKI(pack(p + ".mlp.w2.weight", dd, F, 0, D, F, st));
+      wqkvg.push_back(a); wo.push_back(b); w13.push_back(c); w2.push_back(dd);
+      CKI(pack_vec(p + ".attention.q_norm.weight", qkn + (long)l * 2 * D, D, st));
+      CKI(pack_vec(p + ".attention.k_norm.weight", qkn + (long)l * 2 * D + D, D, st));
+      for (int w = 0; w < 2; ++w)
+        for (int q = 0; q < 3; ++q) {
+          const long z = (long)(2 * l + w) * 3 + q;
+          const std::string ap = p + "." + adn[w] + "." + parts[q];
+          CKI(pack(ap + "_down.weight", mod_down, D, (int)(z * rank_pad), R, D, st));
+          CKI(pack(ap + "_up.weight", mod_up, R, (int)(z * D), D, R, st));
+          CKI(pack_vec(ap + "_up.bias", mod_up_b + z * D, D, st));
+        }
+    }
+    CKI(walloc(&out_norm, 1, D)); CKI(pack_vec("out_norm.weight", out_norm, D, st));
+    CKI(walloc(&out_w, 128, D)); CKI(pack("out_proj.weight", out_w, D, 0, cfg.latent_size, D, st));
+    CKI(walloc(&out_b, 1, 128)); CKI(pack_vec("out_proj.bias", out_b, cfg.latent_size, st));
+    CK(hipStreamSynchronize(st));
+    drop_raw({"text_encoder.", "speaker_encoder.", "latent_encoder.", "text_norm", "speaker_norm", "latent_norm", "cond_module.",
+              "in_proj.", "blocks.", "out_norm", "out_proj."});
+    CK(b_nkeys.reserve(sizeof(int) * 4 * MAXROWS));
+    dit_ready = true;
+    return ECHO_OK;
+  }
+  void drop_raw(const std::vector<std::string>& prefixes) {
+    for (auto it = raw.begin(); it != raw.end();) {
+      bool hit = false;
+      for (auto& p : prefixes) if (it->first.compare(0, p.size(), p) == 0) { hit = true; break; }
+      if (hit) { if (it->second.d) (void)hipFree(it->second.d); it = raw.erase(it); } else ++it;
+    }
+  }
+  int set_rope(const void* t, int npos) override { rope = (const float2*)t; rope_npos = npos; return ECHO_OK; }
+  int set_ae_rope(const void* t, int npos) override { ae_rope = (const float*)t; ae_rope_npos = npos; return ECHO_OK; }
+
+  // ------------------------------------------------------------------ attention dispatch
+  struct SegDesc {
+    const T* K = nullptr; long k_ld = 0, k_row_stride = 0;
+    const T* Vt = nullptr; long vt_ld = 0, vt_row_stride = 0;
+    const float* bias = nullptr; long bias_ld = 0;
+    int kv_mod = 0;       // kv row = row % kv_mod (0: row itself)
+    int maxk = 0;         // max keys over rows (host knowledge)
+    int which = 0;        // slot in the nkeys table (0 self, 1 latent, 2 text, 3 speaker)
+  };
+  // q/gate/out live in [rows*S][..] buffers with per-row stride S*ld
+  int attention(const T* q, long q_ld, const T* gate, long g_ld, T* out, long o_ld, int rows, int S, int H, const SegDesc* segs,
+                int nseg, bool causal, hipStream_t st) {
+    const int* nk = b_nkeys.as<int>();
+    if constexpr (Num<T>::is_bf16) {
+      AttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.Q = q; a.q_ld = q_ld; a.q_row_stride = (long)S * q_ld;
+      a.O = out; a.o_ld = o_ld; a.o_row_stride = (long)S * o_ld;
+      a.G = gate; a.g_ld = g_ld; a.g_row_stride = (long)S * g_ld;
+      a.S = S; a.H = H; a.rows = rows; a.causal = causal ? 1 : 0; a.scale = 1.0f / sqrtf(128.0f);
+      int n = 0;
+      for (int s = 0; s < nseg; ++s) {
+        if (segs[s].maxk <= 0) continue;
+        AttnSeg& g = a.seg[n++];
+        g.K = segs[s].K; g.k_ld = segs[s].k_ld; g.k_row_stride = segs[s].k_row_stride; g.k_head_stride = 128;
+        g.Vt = segs[s].Vt; g.vt_ld = segs[s].vt_ld; g.vt_row_stride = segs[s].vt_row_stride; g.vt_head_stride = 128 * segs[s].vt_ld;
+        g.nkeys = nk + segs[s].which * MAXROWS;
+        g.bias = segs[s].bias; g.bias_row_stride = segs[s].bias_ld;
+        g.kv_mod = segs[s].kv_mod;
+      }
+      a.nseg = n;
+      if (n == 0) return fail("attention without keys");
+      CK(launch_attention_bf16(a, st));
+      return ECHO_OK;
+    } else {
+      return attention_f32(q, q_ld, gate, g_ld, out, o_ld, rows, S, H, segs, nseg, causal, st);
+    }
+  }
+
+  // unfused exact-fp32 attention for parity mode: scores GEMM -> softmax -> PV GEMM
+  int attention_f32(const T* q, long q_ld, const T* gate, long g_ld, T* out, long o_ld, int rows, int S, int H, const SegDesc* segs,
+                    int nseg, bool causal, hipStream_t st) {
+    if constexpr (!Num<T>::is_bf16) {
+      int off[4] = {0, 0, 0, 0}, wdt[4] = {0, 0, 0, 0}, slot[4] = {0, 0, 0, 0};
+      const SegDesc* act[4];
+      int n = 0, tot = 0;
+      for (int s = 0; s < nseg; ++s) {
+        if (segs[s].maxk <= 0) continue;
+        act[n] = &segs[s]; off[n] = tot; wdt[n] = (int)rup(segs[s].maxk, 32); slot[n] = segs[s].which; tot += wdt[n]; ++n;
+      }
+      if (n == 0) return fail("attention without keys");
+      const long ld = tot;
+      CK(b_scores.reserve((size_t)rows * H * S * ld * sizeof(float)));
+      CK(b_biasrows.reserve((size_t)rows * ld * sizeof(float)));
+      CK(b_segmeta.reserve(sizeof(int) * (8 + 4 * MAXROWS)));
+      // nkeys table reordered to the active segments
+      int hmeta[8];
+      for (int i = 0; i < 4; ++i) { hmeta[i] = off[i]; hmeta[4 + i] = wdt[i]; }
+      CK(hipMemcpyAsync(b_segmeta.p, hmeta, sizeof(hmeta), hipMemcpyHostToDevice, st));
+      int* nk_act = b_segmeta.as<int>() + 8;
+      for (int i = 0; i < n; ++i)
+        CK(hipMemcpyAsync(nk_act + i * MAXROWS, b_nkeys.as<int>() + slot[i] * MAXROWS, sizeof(int) * MAXROWS, hipMemcpyDeviceToDevice, st));
+      CK(hipStreamSynchronize(st));  // hmeta is a stack array (parity mode only)
+      const float *b2 = nullptr, *b3 = nullptr; long b2s = 0, b3s = 0; int b2m = 0, b3m = 0;
+      // slots 2/3 of build_bias_kernel refer to ACTIVE segment indices here; map text/speaker biases accordingly
+      float* biasrows = b_biasrows.as<float>();
+      {
+        // generic: write validity first, then add per-key biases segment by segment
+        hipLaunchKernelGGL(build_bias_kernel, dim3((unsigned)(((long)rows * tot + 255) / 256)), dim3(256), 0, st, biasrows, ld, rows, n,
+                           b_segmeta.as<int>(), b_segmeta.as<int>() + 4, nk_act, MAXROWS, b2, b2s, b2m, b3, b3s, b3m, tot);
+        CK(hipGetLastError());
+        for (int i = 0; i < n; ++i)
+          if (act[i]->bias) {
+            // add bias[kvrow][k] to columns off[i].. for every row
+            CKI(add_seg_bias(biasrows, ld, rows, off[i], std::min(wdt[i], (int)act[i]->bias_ld), act[i]->bias, act[i]->bias_ld, act[i]->kv_mod, st));
+          }
+      }
+      float* sc = b_scores.as<float>();
+      const float scale = 1.0f / sqrtf(128.0f);
+      for (int i = 0; i < n; ++i) {
+        const SegDesc& sg = *act[i];
+        const int groups = sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
+        const int per = sg.kv_mod ? sg.kv_mod : rows;
+        for (int gidx = 0; gidx < groups; ++gidx) {
+          const int r0 = gidx * per, nr = std::min(per, rows - r0);
+          GemmArgs g = G(q + (long)r0 * S * q_ld, q_ld, sg.K + (sg.kv_mod ? 0 : (long)r0 * sg.k_row_stride), sg.k_ld,
+                         (T*)(sc + (long)r0 * H * S * ld + off[i]), ld, S, wdt[i], 128);
+          g.nbatch = nr * H; g.nbi = H;
+          g.a_bo = (long)S * q_ld; g.a_bi = 128;
+          g.w_bo = sg.k_row_stride; g.w_bi = 128;
+          g.c_bo = (long)H * S * ld; g.c_bi = (long)S * ld;
+          g.acc_scale = scale;
+          CKI(run(g, st));
+        }
+      }
+      CK(launch_softmax_f32(sc, ld, S, rows * H, tot, tot, biasrows, ld, H, causal ? 1 : 0, 0, st));
+      for (int i = 0; i < n; ++i) {
+        const SegDesc& sg = *act[i];
+        const int groups = sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
+        const int per = sg.kv_mod ? sg.kv_mod : rows;
+        for (int gidx = 0; gidx < groups; ++gidx) {
+          const int r0 = gidx * per, nr = std::min(per, rows - r0);
+          T* o = out + (long)r0 * S * o_ld;
+          GemmArgs g = G((const T*)(sc + (long)r0 * H * S * ld + off[i]), ld, sg.Vt + (sg.kv_mod ? 0 : (long)r0 * sg.vt_row_stride),
+                         sg.vt_ld, o, o_ld, S, 128, wdt[i]);
+          g.nbatch = nr * H; g.nbi = H;
+          g.a_bo = (long)H * S * ld; g.a_bi = (long)S * ld;
+          g.w_bo = sg.vt_row_stride; g.w_bi = 128 * sg.vt_ld;
+          g.c_bo = (long)S * o_ld; g.c_bi = 128;
+          if (i > 0) { g.res = o; g.ldres = o_ld; g.res_bo = g.c_bo; g.res_bi = g.c_bi; }
+          CKI(run(g, st));
+        }
+      }
+      if (gate) {
+        const long n_el = (long)rows * S * H * 128;
+        hipLaunchKernelGGL(gate_mul_kernel<T>, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, out, o_ld, gate, g_ld,
+                           (long)rows * S, H * 128);
+        CK(hipGetLastError());
+      }
+      return ECHO_OK;
+    } else {
+      return fail("attention_f32 called in bf16 mode");
+    }
+  }
+  int add_seg_bias(float* biasrows, long ld, int rows, int off, int w, const float* bias, long bias_ld, int kv_mod, hipStream_t st);
+
+  // ------------------------------------------------------------------ encoders (model.py:392-469)
+  // x: (B*Tn, d) in b_ex.  Runs L blocks in place.
+  int run_encoder(EncW& e, int B, int Tn, bool causal, const SegDesc& self_seg_proto, hipStream_t st) {
+    const int d = e.d, M = B * Tn, F = e.F, H = e.H;
+    const int Tpad = (int)rup(Tn, 64);
+    CK(b_exn.reserve((size_t)(M + 128) * d * sizeof(T)));
+    CK(b_eqkvg.reserve((size_t)(M + 128) * 4 * d * sizeof(T)));
+    CK(b_evt.reserve((size_t)B * d * Tpad * sizeof(T)));
+    CK(b_eattn.reserve((size_t)(M + 128) * d * sizeof(T)));
+    CK(b_eh.reserve((size_t)(M + 128) * F * sizeof(T)));
+    T *x = b_ex.as<T>(), *xn = b_exn.as<T>(), *qkvg = b_eqkvg.as<T>(), *vt = b_evt.as<T>(), *ao = b_eattn.as<T>(), *hh = b_eh.as<T>();
+    for (int i = 0; i < e.L; ++i) {
+      CK(launch_norm<T>(NORM_RMS_W, x, d, xn, d, M, d, cfg.norm_eps, e.an[i], nullptr, st));
+      CKI(run(G(xn, d, e.wqkvg[i], d, qkvg, 4 * d, M, 4 * d, d), st));
+      CK(launch_headnorm_rope_nt<T>(qkvg, 4 * d, d, 2, M, Tn, H, e.qkn + (long)i * 2 * d, d, cfg.norm_eps, 1, H, rope, 0, 1, st));
+      CK(launch_transpose_heads<T>(qkvg + 2 * d, 4 * d, vt, Tpad, (long)d * Tpad, B, Tn, H, 128, st));
+      SegDesc sg = self_seg_proto;
+      sg.K = qkvg + d; sg.k_ld = 4 * d; sg.k_row_stride = (long)Tn * 4 * d;
+      sg.Vt = vt; sg.vt_ld = Tpad; sg.vt_row_stride = (long)d * Tpad;
+      CKI(attention(qkvg, 4 * d, qkvg + 3 * d, 4 * d, ao, d, B, Tn, H, &sg, 1, causal, st));
+      GemmArgs g = G(ao, d, e.wo[i], d, x, d, M, d, d);
+      g.res = x; g.ldres = d;
+      CKI(run(g, st));
+      CK(launch_norm<T>(NORM_RMS_W, x, d, xn, d, M, d, cfg.norm_eps, e.mn[i], nullptr, st));
+      GemmArgs g1 = G(xn, d, e.w13[i], d, hh, F, M, 2 * F, d);
+      g1.swiglu = 1;
+      CKI(run(g1, st));
+      GemmArgs g2 = G(hh, F, e.w2[i], F, x, d, M, d, F);
+      g2.res = x; g2.ldres = d;
+      CKI(run(g2, st));
+    }
+    return ECHO_OK;
+  }
+
+  // after the encoder: final norm, K/V projection for all DiT layers, k_norm (+ optional RoPE), Vᵀ
+  int project_kv(EncW& e, int B, int Tn, DevBuf& b_kv, DevBuf& b_vt, int& pad_rows, int& vld, bool rope_keys, hipStream_t st) {
+    const int D = cfg.model_size, L = cfg.num_layers, H = cfg.num_heads, M = B * Tn;
+    const long ld = (long)L * 2 * D;
+    pad_rows = (int)rup(Tn, 128);
+    vld = (int)rup(Tn, 64);
+    CK(b_kv.reserve((size_t)((long)B * Tn + 256) * ld * sizeof(T)));
+    CK(b_vt.reserve((size_t)L * B * D * vld * sizeof(T) + 4096));
+    T *x = b_ex.as<T>(), *xn = b_exn.as<T>(), *kv = b_kv.as<T>(), *vt = b_vt.as<T>();
+    CK(launch_norm<T>(NORM_RMS_W, x, e.d, xn, e.d, M, e.d, cfg.norm_eps, e.out_norm, nullptr, st));
+    CKI(run(G(xn, e.d, e.kv_w, e.d, kv, ld, M, L * 2 * D, e.d), st));
+    // k_norm of each DiT layer (model.py:274,281,289) on that layer's K columns; latent keys also get half-head RoPE at 4*i
+    CK(launch_headnorm_rope_nt<T>(kv, ld, 2 * D, L, M, Tn, H, qkn + D, 2 * D, cfg.norm_eps, 1, rope_keys ? H / 2 : 0, rope, 0,
+                                  cfg.speaker_patch_size, st));
+    for (int l = 0; l < L; ++l)
+      CK(launch_transpose_heads<T>(kv + (long)l * 2 * D + D, ld, vt + (long)l * B * D * vld, vld, (long)D * vld, B, Tn, H, 128, st));
+    return ECHO_OK;
+  }
+
+  int upload_bias(const float* bias, int B, int Tt, DevBuf& dst, bool& has, long& ldb, hipStream_t st) {
+    has = bias != nullptr;
+    ldb = Tt;
+    if (has) {
+      CK(dst.reserve((size_t)B * Tt * sizeof(float)));
+      CK(hipMemcpyAsync(dst.p, bias, (size_t)B * Tt * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    return ECHO_OK;
+  }
+  int encode_text(const int32_t* ids, const float* bias, const int32_t* nk, int B, int Tt, hipStream_t st) override {
+    if (!dit_ready) return fail("echo_finalize_dit was not called");
+    if (B < 1 || 3 * B > MAXROWS) return fail("unsupported batch size");
+    if (!rope) return fail("rope table not set");
+    kvB = B;
+    text_nk.assign(nk, nk + B);
+    int Te = 0;
+    for (int b = 0; b < B; ++b) { if (nk[b] < 0 || nk[b] > Tt) return fail("bad text nkeys"); Te = std::max(Te, nk[b]); }
+    text_T = Te;
+    if (Te == 0) return ECHO_OK;
+    if (Te > rope_npos) return fail("rope table too short");
+    CKI(upload_bias(bias, B, Tt, b_bias_text, text_has_bias, text_bias_ld, st));
+    const int d = tenc.d;
+    CK(b_ex.reserve((size_t)((long)B * Te + 128) * d * sizeof(T)));
+    CK(b_ein.reserve((size_t)B * Te * sizeof(int)));
+    // gather the first Te ids of every batch row
+    CK(hipMemcpy2DAsync(b_ein.p, Te * sizeof(int), ids, Tt * sizeof(int), Te * sizeof(int), B, hipMemcpyDeviceToDevice, st));
+    CK(launch_embedding<T>(b_ein.as<int>(), text_emb, b_ex.as<T>(), d, B * Te, d, st));
+    // encoder self-attention: keys = valid prefix (+ optional bias), rows here are the B batch items
+    CKI(push_nkeys_for_encoder(text_nk, st));
+    SegDesc proto;
+    proto.which = 0; proto.maxk = Te; proto.kv_mod = 0;
+    proto.bias = text_has_bias ? b_bias_text.as<float>() : nullptr; proto.bias_ld = text_bias_ld;
+    CKI(run_encoder(tenc, B, Te, false, proto, st));
+    CKI(project_kv(tenc, B, Te, b_kv_text, b_vt_text, text_pad, text_vld, false, st));
+    return ECHO_OK;
+  }
+
+  std::vector<int> host_nk = std::vector<int>(4 * MAXROWS, 0);
+  int push_nkeys(hipStream_t st) {
+    CK(hipMemcpyAsync(b_nkeys.p, host_nk.data(), host_nk.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    CK(hipStreamSynchronize(st));
+    return ECHO_OK;
+  }
+  int push_nkeys_for_encoder(const std::vector<int>& nk, hipStream_t st) {
+    for (int i = 0; i < MAXROWS; ++i) host_nk[i] = i < (int)nk.size() ? nk[i] : 0;
+    return push_nkeys(st);
+  }
+
+  int encode_patches(EncW& e, const void* lat, long row_stride, int B, int npatch, hipStream_t st) {
+    // lat: (B, npatch*patch, latent) of T with batch stride row_stride elements; x = (in_proj(patches) + b) / 6  (model.py:459-462)
+    const int d = e.d, K = e.in_k;
+    CK(b_ex.reserve((size_t)((long)B * npatch + 128) * d * sizeof(T)));
+    GemmArgs g = G((const T*)lat, K, e.in_w, K, b_ex.as<T>(), d, npatch, d, K);
+    g.nbatch = B; g.nbi = 1; g.a_bo = row_stride; g.c_bo = (long)npatch * d;
+    g.bias = e.in_b; g.div = 6.0f;
+    CKI(run(g, st));
+    return ECHO_OK;
+  }
+
+  int encode_speaker(const void* lat, const float* bias, const int32_t* nk, int B, int Ts, hipStream_t st) override {
+    if (!dit_ready) return fail("echo_finalize_dit was not called");
+    if (B < 1 || 3 * B > MAXROWS) return fail("unsupported batch size");
+    if (!rope) return fail("rope table not set");
+    const int ps = cfg.speaker_patch_size;
+    if (Ts % ps) return fail("speaker latent length must be a multiple of the patch size");
+    kvB = B;
+    spk_nk.assign(nk, nk + B);
+    int Se = 0;
+    for (int b = 0; b < B; ++b) { if (nk[b] < 0 || nk[b] > Ts / ps) return fail("bad speaker nkeys"); Se = std::max(Se, nk[b]); }
+    spk_T = Se;
+    if (Se == 0) return ECHO_OK;   // no speaker reference: one always-masked key in the reference, zero keys here
+    if (Se > rope_npos) return fail("rope table too short");
+    CKI(upload_bias(bias, B, Ts / ps, b_bias_spk, spk_has_bias, spk_bias_ld, st));
+    CKI(encode_patches(senc, lat, (long)Ts * cfg.latent_size, B, Se, st));
+    std::vector<int> full(B, Se);   // SpeakerEncoder attends causally with no key mask (model.py:467)
+    CKI(push_nkeys_for_encoder(full, st));
+    SegDesc proto;
+    proto.which = 0; proto.maxk = Se;
+    CKI(run_encoder(senc, B, Se, true, proto, st));
+    CKI(project_kv(senc, B, Se, b_kv_spk, b_vt_spk, spk_pad, spk_vld, false, st));
+    return ECHO_OK;
+  }
+
+  int encode_latent(const void* lat, int B, int n_latents, long row_stride, hipStream_t st) override {
+    if (!dit_ready || !cfg.has_latent_encoder) return fail("latent encoder not available");
+    const int ps = cfg.speaker_patch_size;
+    if (n_latents % ps) return fail("prefix length must be a multiple of the patch size");
+    latB = B;
+    lat_T = n_latents / ps;
+    if (lat_T == 0) return ECHO_OK;
+    if (lat_T * ps > rope_npos) return fail("rope table too short");
+    CKI(encode_patches(lenc, lat, row_stride, B, lat_T, st));
+    std::vector<int> full(B, lat_T);
+    CKI(push_nkeys_for_encoder(full, st));
+    SegDesc proto;
+    proto.which = 0; proto.maxk = lat_T;
+    CKI(run_encoder(lenc, B, lat_T, true, proto, st));
+    CKI(project_kv(lenc, B, lat_T, b_kv_lat, b_vt_lat, lat_pad_rows, lat_vld, true, st));
+    return ECHO_OK;
+  }
+
+  int scale_speaker_kv(float s, int max_layers, hipStream_t st) override {
+    if (spk_T == 0) return ECHO_OK;
+    const int D = cfg.model_size, L = cfg.num_layers;
+    const int n = max_layers < 0 ? L : std::min(max_layers, L);
+    const long ld = (long)L * 2 * D;
+    for (int l = 0; l < n; ++l) {
+      CK(launch_scale_2d<T>(b_kv_spk.as<T>() + (long)l * 2 * D, ld, kvB * spk_T, 2 * D, s, st));
+      // the transposed copy of V follows (same elementwise product, same rounding)
+      CK(launch_scale_2d<T>(b_vt_spk.as<T>() + (long)l * kvB * D * spk_vld, spk_vld, kvB * D, spk_T, s, st));
+    }
+    return ECHO_OK;
+  }
+
+  int debug_get_kv(int which, int layer, float* k, float* v, int* Bo, int* To) override {
+    const int D = cfg.model_size, L = cfg.num_layers;
+    const long ld = (long)L * 2 * D;
+    DevBuf* kv = which == 0 ? &b_kv_text : which == 1 ? &b_kv_spk : &b_kv_lat;
+    const int Tn = which == 0 ? text_T : which == 1 ? spk_T : lat_T;
+    const int B = which == 2 ? latB : kvB;
+    if (Bo) *Bo = B;
+    if (To) *To = Tn;
+    if (!k || !v || Tn == 0) return ECHO_OK;
+    if (layer < 0 || layer >= L) return fail("bad layer");
+    CK(launch_convert_to_f32<T>(kv->as<T>() + (long)layer * 2 * D, ld, k, D, B * Tn, D, nullptr));
+    CK(launch_convert_to_f32<T>(kv->as<T>() + (long)layer * 2 * D + D, ld, v, D, B * Tn, D, nullptr));
+    CK(hipDeviceSynchronize());
+    return ECHO_OK;
+  }
+
+  // ------------------------------------------------------------------ EchoDiT forward (model.py:563-604)
+  int reserve_dit_ws(int M, int rows, int S) {
+    const int D = cfg.model_size, F = cfg.intermediate_size;
+    const int Sp = (int)rup(S, 64);
+    CK(b_xin.reserve((size_t)(M + 128) * lat_pad * sizeof(T)));
+    CK(b_x.reserve((size_t)(M + 128) * D * sizeof(T)));
+    CK(b_xn.reserve((size_t)(M + 128) * D * sizeof(T)));
+    CK(b_qkvg.reserve((size_t)(M + 256) * 4 * D * sizeof(T)));
+    CK(b_vt_self.reserve((size_t)rows * D * Sp * sizeof(T) + 4096));
+    CK(b_attn.reserve((size_t)(M + 128) * D * sizeof(T)));
+    CK(b_h.reserve((size_t)(M + 128) * F * sizeof(T)));
+    CK(b_vout.reserve((size_t)(M + 128) * 128 * sizeof(T)));
+    return ECHO_OK;
+  }
+  // host_nk rows must already describe this forward (set_row_keys)
+  void set_row_keys(int rows, int B, int S, int start_pos, bool use_latent, const int32_t* ton, const int32_t* son) {
+    for (int r = 0; r < MAXROWS; ++r) {
+      const int b = B > 0 ? r % B : 0;
+      const bool in = r < rows;
+      host_nk[0 * MAXROWS + r] = in ? S : 0;
+      int nl = 0;
+      if (in && use_latent && lat_T > 0) nl = std::min(lat_T, (start_pos + cfg.speaker_patch_size - 1) / cfg.speaker_patch_size);
+      host_nk[1 * MAXROWS + r] = nl;
+      host_nk[2 * MAXROWS + r] = (in && text_T > 0 && (!ton || ton[r])) ? text_nk[b] : 0;
+      host_nk[3 * MAXROWS + r] = (in && spk_T > 0 && (!son || son[r])) ? spk_nk[b] : 0;
+    }
+  }
+
+  // xin (rows*S, lat_pad) -> vout (rows*S, 128); modrow = this step's [2L][3][D] modulation table
+  int forward_rows(int rows, int B, int S, int start_pos, bool use_latent, const T* modrow, hipStream_t st) {
+    const int D = cfg.model_size, L = cfg.num_layers, H = cfg.num_heads, F = cfg.intermediate_size, M = rows * S;
+    const int Sp = (int)rup(S, 64);
+    T *xin = b_xin.as<T>(), *x = b_x.as<T>(), *xn = b_xn.as<T>(), *qkvg = b_qkvg.as<T>(), *vts = b_vt_self.as<T>(),
+      *ao = b_attn.as<T>(), *hh = b_h.as<T>(), *vout = b_vout.as<T>();
+    if (start_pos + S > rope_npos) return fail("rope table too short");
+    {
+      GemmArgs g = G(xin, lat_pad, in_w, lat_pad, x, D, M, D, lat_pad);
+      g.bias = in_b;
+      CKI(run(g, st));
+    }
+    const long kvld = (long)L * 2 * D;
+    int max_lat = 0, max_text = 0, max_spk = 0;
+    for (int r = 0; r < rows; ++r) {
+      max_lat = std::max(max_lat, host_nk[1 * MAXROWS + r]);
+      max_text = std::max(max_text, host_nk[2 * MAXROWS + r]);
+      max_spk = std::max(max_spk, host_nk[3 * MAXROWS + r]);
+    }
+    for (int l = 0; l < L; ++l) {
+      const T* ma = modrow + (long)(2 * l) * 3 * D;
+      const T* mm = modrow + (long)(2 * l + 1) * 3 * D;
+      CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, ma + D, ma, st));
+      CKI(run(G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D), st));
+      CK(launch_headnorm_rope_nt<T>(qkvg, 4 * D, D, 2, M, S, H, qkn + (long)l * 2 * D, D, cfg.norm_eps, 1, H / 2, rope, start_pos, 1, st));
+      CK(launch_transpose_heads<T>(qkvg + 2 * D, 4 * D, vts, Sp, (long)D * Sp, rows, S, H, 128, st));
+      SegDesc sg[4];
+      sg[0].which = 0; sg[0].maxk = S; sg[0].K = qkvg + D; sg[0].k_ld = 4 * D; sg[0].k_row_stride = (long)S * 4 * D;
+      sg[0].Vt = vts; sg[0].vt_ld = Sp; sg[0].vt_row_stride = (long)D * Sp;
+      sg[1].which = 1; sg[1].maxk = max_lat; sg[1].kv_mod = latB;
+      if (max_lat > 0) {
+        sg[1].K = b_kv_lat.as<T>() + (long)l * 2 * D; sg[1].k_ld = kvld; sg[1].k_row_stride = (long)lat_T * kvld;
+        sg[1].Vt = b_vt_lat.as<T>() + (long)l * latB * D * lat_vld; sg[1].vt_ld = lat_vld; sg[1].vt_row_stride = (long)D * lat_vld;
+      }
+      sg[2].which = 2; sg[2].maxk = max_text; sg[2].kv_mod = kvB;
+      if (max_text > 0) {
+        sg[2].K = b_kv_text.as<T>() + (long)l * 2 * D; sg[2].k_ld = kvld; sg[2].k_row_stride = (long)text_T * kvld;
+        sg[2].Vt = b_vt_text.as<T>() + (long)l * kvB * D * text_vld; sg[2].vt_ld = text_vld; sg[2].vt_row_stride = (long)D * text_vld;
+        if (text_has_bias) { sg[2].bias = b_bias_text.as<float>(); sg[2].bias_ld = text_bias_ld; }
+      }
+      sg[3].which = 3; sg[3].maxk = max_spk; sg[3].kv_mod = kvB;
+      if (max_spk > 0) {
+        sg[3].K = b_kv_spk.as<T>() + (long)l * 2 * D; sg[3].k_ld = kvld; sg[3].k_row_stride = (long)spk_T * kvld;
+        sg[3].Vt = b_vt_spk.as<T>() + (long)l * kvB * D * spk_vld; sg[3].vt_ld = spk_vld; sg[3].vt_row_stride = (long)D * spk_vld;
+        if (spk_has_bias) { sg[3].bias = b_bias_spk.as<float>(); sg[3].bias_ld = spk_bias_ld; }
+      }
+      CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st));
+      {
+        GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
+        g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
+        CKI(run(g, st));
+      }
+      CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, mm + D, mm, st));
+      {
+        GemmArgs g = G(xn, D, w13[l], D, hh, F, M, 2 * F, D);
+        g.swiglu = 1;
+        CKI(run(g, st));
+      }
+      {
+        GemmArgs g = G(hh, F, w2[l], F, x, D, M, D, F);
+        g.colscale = mm + 2 * D; g.res = x; g.ldres = D;
+        CKI(run(g, st));
+      }
+    }
+    CK(launch_norm<T>(NORM_RMS_W, x, D, xn, D, M, D, cfg.norm_eps, out_norm, nullptr, st));
+    {
+      GemmArgs g = G(xn, D, out_w, D, vout, 128, M, cfg.latent_size, D);
+      g.bias = out_b;
+      CKI(run(g, st));
+    }
+    return ECHO_OK;
+  }
+
+  // modulation tables for N timesteps (model.py:583, 70-74, 79-81): mod[n][2L][3][D]
+  int compute_mod(const T* temb, int N, hipStream_t st) {
+    const int D = cfg.model_size, L = cfg.num_layers, E = cfg.timestep_embed_size, R = cfg.adaln_rank;
+    const int A = 2 * L * 3;
+    CK(b_mod.reserve((size_t)(N + 128) * A * D * sizeof(T)));
+    CK(b_c1.reserve((size_t)(N + 128) * D * sizeof(T)));
+    CK(b_c2.reserve((size_t)(N + 128) * D * sizeof(T)));
+    CK(b_cond.reserve((size_t)(N + 128) * 3 * D * sizeof(T)));
+    CK(b_sc.reserve((size_t)(N + 128) * 3 * D * sizeof(T)));
+    CK(b_dn.reserve((size_t)A * (N + 128) * R * sizeof(T)));
+    T *c1 = b_c1.as<T>(), *c2 = b_c2.as<T>(), *cond = b_cond.as<T>(), *sc = b_sc.as<T>(), *dn = b_dn.as<T>(), *mod = b_mod.as<T>();
+    { GemmArgs g = G(temb, E, cond0, E, c1, D, N, D, E); g.act = 1; CKI(run(g, st)); }
+    { GemmArgs g = G(c1, D, cond2, D, c2, D, N, D, D); g.act = 1; CKI(run(g, st)); }
+    CKI(run(G(c2, D, cond4, D, cond, 3 * D, N, 3 * D, D), st));
+    CK(launch_silu<T>(cond, sc, (long)N * 3 * D, st));
+    {
+      GemmArgs g = G(sc, 3 * D, mod_down, D, dn, R, N, R, D);
+      g.nbatch = A; g.nbi = 3;
+      g.a_bo = 0; g.a_bi = D;
+      g.w_bo = 3L * rank_pad * D; g.w_bi = (long)rank_pad * D;
+      g.c_bo = 3L * N * R; g.c_bi = (long)N * R;
+      CKI(run(g, st));
+    }
+    {
+      GemmArgs g = G(dn, R, mod_up, R, mod, (long)A * D, N, D, R);
+      g.nbatch = A; g.nbi = 3;
+      g.a_bo = 3L * N * R; g.a_bi = (long)N * R;
+      g.w_bo = 3L * D * R; g.w_bi = (long)D * R;
+      g.c_bo = 3L * D; g.c_bi = D;
+      g.bias = mod_up_b; g.bias_bo = 3L * D; g.bias_bi = D;
+      g.res = cond; g.ldres = 3 * D; g.res_bo = 0; g.res_bi = D;
+      CKI(run(g, st));
+    }
+    CK(launch_mod_finalize<T>(mod, (long)N * 2 * L, D, st));
+    return ECHO_OK;
+  }
+
+  int dit_forward(const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent, const int32_t* ton,
+                  const int32_t* son, float* v, hipStream_t st) override {
+    if (!dit_ready) return fail("echo_finalize_dit was not called");
+    if (rows < 1 || rows > MAXROWS || B < 1 || rows % B || B != kvB) return fail("bad rows/B");
+    const int M = rows * S;
+    CKI(reserve_dit_ws(M, rows, S));
+    CKI(compute_mod((const T*)temb, 1, st));
+    set_row_keys(rows, B, S, start_pos, use_latent != 0, ton, son);
+    CKI(push_nkeys(st));
+    // x (M, latent) -> xin (M, lat_pad) zero padded
+    CK(hipMemcpy2DAsync(b_xin.p, lat_pad * sizeof(T), x, cfg.latent_size * sizeof(T), cfg.latent_size * sizeof(T), M,
+                        hipMemcpyDeviceToDevice, st));
+    CKI(forward_rows(rows, B, S, start_pos, use_latent != 0, b_mod.as<T>(), st));
+    CK(launch_convert_to_f32<T>(b_vout.as<T>(), 128, v, cfg.latent_size, M, cfg.latent_size, st));
+    return ECHO_OK;
+  }
+
+  // ------------------------------------------------------------------ sampler (inference.py:427-517)
+  int sample_euler(const echo_sampler_params* p, const float* x0, float* out, hipStream_t st) override {
+    if (!dit_ready) return fail("echo_finalize_dit was not called");
+    const int B = p->B, S = p->S, N = p->num_steps, Lz = cfg.latent_size;
+    if (B != kvB || 3 * B > MAXROWS || S < 1 || N < 1) return fail("bad sampler params");
+    const int rows3 = 3 * B;
+    CKI(reserve_dit_ws(rows3 * S, rows3, S));
+    CK(b_xstate.reserve((size_t)B * S * Lz * sizeof(float)));
+    float* xs = b_xstate.as<float>();
+    if (profiling) {
+      for (auto& e : ev) if (!e) CK(hipEventCreate(&e));
+      gemm_events_used = 0;
+      CK(hipEventRecord(ev[0], st));
+    }
+    CK(hipMemcpyAsync(xs, x0, (size_t)B * S * Lz * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CKI(compute_mod((const T*)p->temb, N, st));
+    if (profiling) CK(hipEventRecord(ev[1], st));
+    // CFG row layout: rows [0,B) cond, [B,2B) text-uncond, [2B,3B) speaker-uncond (inference.py:474-475)
+    std::vector<int32_t> ton(rows3, 1), son(rows3, 1);
+    for (int b = 0; b < B; ++b) { ton[B + b] = 0; son[2 * B + b] = 0; }
+    set_row_keys(rows3, B, S, p->start_pos, p->use_latent != 0, ton.data(), son.data());
+    CKI(push_nkeys(st));
+    const long modstride = (long)2 * cfg.num_layers * 3 * cfg.model_size;
+    EulerArgs e;
+    memset(&e, 0, sizeof(e));
+    e.x = xs; e.v = b_vout.p; e.ldv = 128; e.xin = b_xin.p; e.ld_xin = lat_pad;
+    e.B = B; e.S = S; e.L = Lz; e.R = 1;
+    e.R_next = p->steps[0].has_cfg ? 3 : 1;
+    e.init_scale = p->init_scale == 0.0f ? 1.0f : p->init_scale;
+    CK(launch_euler<T>(e, st));
+    for (int i = 0; i < N; ++i) {
+      const echo_step& sp = p->steps[i];
+      const int rows = sp.has_cfg ? rows3 : B;
+      CKI(forward_rows(rows, B, S, p->start_pos, p->use_latent != 0, b_mod.as<T>() + (long)i * modstride, st));
+      if (sp.kv_unscale_after) CKI(scale_speaker_kv(1.0f / p->kv_scale, p->kv_max_layers, st));
+      e.init_scale = 0.0f;
+      e.R = sp.has_cfg ? 3 : 1;
+      e.R_next = (i + 1 < N && p->steps[i + 1].has_cfg) ? 3 : 1;
+      e.s_text = p->cfg_scale_text; e.s_spk = p->cfg_scale_speaker;
+      e.rescale = sp.rescale; e.r_inv1mt = sp.r_inv1mt; e.r_ratio = sp.r_ratio; e.r_1mt = sp.r_1mt;
+      e.dt = sp.dt;
+      CK(launch_euler<T>(e, st));
+    }
+    CK(hipMemcpyAsync(out, xs, (size_t)B * S * Lz * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (profiling) {
+      CK(hipEventRecord(ev[2], st));
+      CK(hipEventSynchronize(ev[2]));
+      CK(hipEventElapsedTime(&prof.ms_mod, ev[0], ev[1]));
+      CK(hipEventElapsedTime(&prof.ms_steps, ev[1], ev[2]));
+      prof.ms_total = prof.ms_mod + prof.ms_steps;
+      collect_gemm_times();
+    }
+    return ECHO_OK;
+  }
+  void collect_gemm_times() {
+    prof.ms_gemm_sum = 0.f; prof.n_gemm = 0;
+    for (size_t i = 0; i < gemm_events_used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) == hipSuccess) { prof.ms_gemm_sum += ms; ++prof.n_gemm; }
+    }
+  }
+
+  // ------------------------------------------------------------------ Fish S1-DAC decode (fp32 weights/activations)
+  struct DacLayer { float *wqkv, *wo, *w13, *w2, *an, *fn, *ga, *gf; };
+  struct DacUp { float *w, *b, *dw, *db, *lnw, *lnb, *p1w, *p1b, *p2w, *p2b, *gamma; int f; };
+  struct DacRU { float *a0, *w7, *b7, *a1, *w1, *b1; };
+  struct DacBlock { float *alpha, *wt, *bt; DacRU ru[3]; int ci, co, r; };
+  std::vector<DacLayer> dpost; float* dpost_norm = nullptr;
+  std::vector<DacUp> dups;
+  float *dconv0_w = nullptr, *dconv0_b = nullptr, *dfinal_alpha = nullptr, *dout_w = nullptr, *pca_w = nullptr, *pca_b = nullptr;
+  float dout_b = 0.f;
+  std::vector<DacBlock> dblocks;
+  int pca_kpad = 0;
+
+  int fpack(const std::string& name, float** dst, long rows_pad, int rows, int cols, long cols_pad, hipStream_t st, int swh = -1, float** existing = nullptr) {
+    const RawTensor* r = find(name);
+    if (!r) return fail("missing tensor: " + name);
+    if (r->numel != (long)rows * cols) return fail("shape mismatch for " + name + " (" + std::to_string(r->numel) + " vs " + std::to_string((long)rows * cols) + ")");
+    if (!existing) { CK(alloc_zero((void**)dst, (size_t)rows_pad * cols_pad * sizeof(float))); } else { *dst = *existing; }
+    CK(launch_pack_rows(r->d, r->dtype, cols, *dst, ECHO_F32, cols_pad, rows, cols, 0, swh, st));
+    return ECHO_OK;
+  }
+  int fvec(const std::string& name, float** dst, int n, hipStream_t st) { return fpack(name, dst, 1, 1, n, rup(n, 4), st); }
+
+  int finalize_dac(hipStream_t st) override {
+    const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
+    if (C % 32 || C > 1024 || (nh * hd) % 32 || ff % 64 || hd != 64 || C != nh * hd) return fail("unsupported DAC sizes");
+    const std::string pm = "quantizer.post_module";
+    for (int i = 0; i < cfg.dac_post_layers; ++i) {
+      const std::string lp = pm + ".layers." + std::to_string(i);
+      DacLayer L{};
+      CKI(fpack(lp + ".attention.wqkv.weight", &L.wqkv, rup(3 * nh * hd, 128), 3 * nh * hd, C, C, st));
+      CKI(fpack(lp + ".attention.wo.weight", &L.wo, rup(C, 128), C, nh * hd, nh * hd, st));
+      CKI(fpack(lp + ".feed_forward.w1.weight", &L.w13, rup(2 * ff, 128), ff, C, C, st, 0));
+      CKI(fpack(lp + ".feed_forward.w3.weight", &L.w13, rup(2 * ff, 128), ff, C, C, st, 1, &L.w13));
+      CKI(fpack(lp + ".feed_forward.w2.weight", &L.w2, rup(C, 128), C, ff, ff, st));
+      CKI(fvec(lp + ".attention_norm.weight", &L.an, C, st));
+      CKI(fvec(lp + ".ffn_norm.weight", &L.fn, C, st));
+      CKI(fvec(lp + ".attention_layer_scale.gamma", &L.ga, C, st));
+      CKI(fvec(lp + ".ffn_layer_scale.gamma", &L.gf, C, st));
+      dpost.push_back(L);
+    }
+    CKI(fvec(pm + ".norm.weight", &dpost_norm, C, st));
+    for (int i = 0; i < cfg.dac_n_up; ++i) {
+      const std::string up = "quantizer.upsample." + std::to_string(i);
+      DacUp U{};
+      U.f = cfg.dac_up_factors[cfg.dac_n_up - 1 - i];
+      CKI(fpack(up + ".0.conv.weight", &U.w, rup(U.f * C, 128), U.f * C, C, C, st));           // (f*Co, Ci), GEMM form
+      CKI(fvec(up + ".0.conv.bias", &U.b, C, st));
+      CKI(fpack(up + ".1.dwconv.conv.weight", &U.dw, C, C, 7, 7, st));
+      CKI(fvec(up + ".1.dwconv.conv.bias", &U.db, C, st));
+      CKI(fvec(up + ".1.norm.weight", &U.lnw, C, st));
+      CKI(fvec(up + ".1.norm.bias", &U.lnb, C, st));
+      CKI(fpack(up + ".1.pwconv1.weight", &U.p1w, rup(4 * C, 128), 4 * C, C, C, st));
+      CKI(fvec(up + ".1.pwconv1.bias", &U.p1b, 4 * C, st));
+      CKI(fpack(up + ".1.pwconv2.weight", &U.p2w, rup(C, 128), C, 4 * C, 4 * C, st));
+      CKI(fvec(up + ".1.pwconv2.bias", &U.p2b, C, st));
+      CKI(fvec(up + ".1.gamma", &U.gamma, C, st));
+      dups.push_back(U);
+    }
+    const std::string dm = "decoder.model";
+    int ch = cfg.dac_decoder_dim;
+    if (ch % 32) return fail("decoder_dim must be a multiple of 32");
+    CKI(fpack(dm + ".0.conv.weight", &dconv0_w, rup(ch, 128), ch, 7 * C, 7 * C, st));          // (Co, 7*Ci)
+    CKI(fvec(dm + ".0.conv.bias", &dconv0_b, ch, st));
+    const int nr = cfg.dac_n_rates;
+    for (int i = 0; i < nr; ++i) {
+      DacBlock Bk{};
+      Bk.ci = ch >> i; Bk.co = ch >> (i + 1); Bk.r = cfg.dac_rates[i];
+      if (Bk.co % 32) return fail("decoder channel counts must be multiples of 32");
+      const std::string bp = dm + "." + std::to_string(i + 1) + ".block";
+      CKI(fvec(bp + ".0.alpha", &Bk.alpha, Bk.ci, st));
+      CKI(fpack(bp + ".1.conv.weight", &Bk.wt, rup(Bk.r * Bk.co, 128), Bk.r * Bk.co, 2 * Bk.ci, 2 * Bk.ci, st));  // (r*Co, 2*Ci)
+      CKI(fvec(bp + ".1.conv.bias", &Bk.bt, Bk.co, st));
+      for (int j = 0; j < 3; ++j) {
+        const std::string rp = bp + "." + std::to_string(2 + j) + ".block";
+        DacRU& ru = Bk.ru[j];
+        CKI(fvec(rp + ".0.alpha", &ru.a0, Bk.co, st));
+        CKI(fpack(rp + ".1.conv.weight", &ru.w7, rup(Bk.co, 128), Bk.co, 7 * Bk.co, 7 * Bk.co, st));
+        CKI(fvec(rp + ".1.conv.bias", &ru.b7, Bk.co, st));
+        CKI(fvec(rp + ".2.alpha", &ru.a1, Bk.co, st));
+        CKI(fpack(rp + ".3.conv.weight", &ru.w1, rup(Bk.co, 128), Bk.co, Bk.co, Bk.co, st));
+        CKI(fvec(rp + ".3.conv.bias", &ru.b1, Bk.co, st));
+      }
+      dblocks.push_back(Bk);
+    }
+    const int cl = ch >> nr;
+    CKI(fvec(dm + "." + std::to_string(nr + 1) + ".alpha", &dfinal_alpha, cl, st));
+    CKI(fpack(dm + "." + std::to_string(nr + 2) + ".conv.weight", &dout_w, 7, 7, cl, cl, st));    // (7, C)
+    {
+      const RawTensor* r = find(dm + "." + std::to_string(nr + 2) + ".conv.bias");
+      if (!r || r->numel != 1) return fail("missing decoder output bias");
+      float* tmp; CK(alloc_zero((void**)&tmp, 16));
+      CK(launch_convert_any(r->d, r->dtype, tmp, ECHO_F32, 1, st));
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(&dout_b, tmp, sizeof(float), hipMemcpyDeviceToHost));
+    }
+    pca_kpad = (int)rup(cfg.latent_size, 32);
+    CK(alloc_zero((void**)&pca_w, (size_t)rup(C, 128) * pca_kpad * sizeof(float)));
+    CK(alloc_zero((void**)&pca_b, (size_t)rup(C, 4) * sizeof(float)));
+    CK(hipStreamSynchronize(st));
+    drop_raw({"quantizer.", "decoder."});
+    dac_ready = true;
+    return ECHO_OK;
+  }
+
+  int frun(const GemmArgs& g, hipStream_t st) {
+    if (profiling) {
+      if (gemm_events_used == gemm_events.size()) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        gemm_events.emplace_back(a, b);
+      }
+      auto& e = gemm_events[gemm_events_used++];
+      CK(hipEventRecord(e.first, st));
+      CK(launch_gemm_nt<float>(g, st));
+      CK(hipEventRecord(e.second, st));
+      return ECHO_OK;
+    }
+    CK(launch_gemm_nt<float>(g, st));
+    return ECHO_OK;
+  }
+  static GemmArgs FG(const float* A, long lda, const float* W, long ldw, float* C, long ldc, long M, int N, int K) {
+    GemmArgs g;
+    gemm_args_init(&g);
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
+    g.Npad = (int)rup(N, 128);
+    return g;
+  }
+
+  // PCA inverse operands (inference.py:228): w = componentsᵀ as (C, latent) row-major, mean (C)
+  int set_pca(const float* w, const float* mean, int on_device, hipStream_t st) override {
+    if (!dac_ready) return fail("echo_finalize_dac was not called");
+    const int C = cfg.dac_latent_dim, Lz = cfg.latent_size;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    CK(hipMemcpy2DAsync(pca_w, pca_kpad * sizeof(float), w, Lz * sizeof(float), Lz * sizeof(float), C, kind, st));
+    CK(hipMemcpyAsync(pca_b, mean, C * sizeof(float), kind, st));
+    CK(hipStreamSynchronize(st));
+    pca_set = true;
+    return ECHO_OK;
+  }
+  bool pca_set = false;
+  int dac_decode(const float* lat, int Tn, float latent_scale, float* wav, hipStream_t st) override {
+    if (!pca_set) return fail("echo_set_pca was not called");
+    return dac_run(lat, nullptr, Tn, latent_scale, wav, st);
+  }
+  int dac_decode_zq(const float* z, int Tn, float* wav, hipStream_t st) override { return dac_run(nullptr, z, Tn, 1.0f, wav, st); }
+
+  // lat: (T, latent) latents (PCA applied here)  OR  zq: (T, C) channels-last quantizer output
+  int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st) {
+    if (!dac_ready) return fail("echo_finalize_dac was not called");
+    if (!ae_rope || Tn > ae_rope_npos) return fail("ae rope table missing or too short");
+    const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
+    long hop = 1;
+    for (int i = 0; i < cfg.dac_n_rates; ++i) hop *= cfg.dac_rates[i];
+    long upf = 1;
+    for (int i = 0; i < cfg.dac_n_up; ++i) upf *= cfg.dac_up_factors[i];
+    // largest activation: rows * channels after each decoder block
+    long maxel = (long)Tn * upf * std::max(C * 4, cfg.dac_decoder_dim);
+    {
+      long rows = (long)Tn * upf;
+      for (auto& b : dblocks) { rows *= b.r; maxel = std::max(maxel, rows * b.co); }
+    }
+    const long PADF = 64L * std::max(cfg.dac_decoder_dim, 4 * C);   // zero rows in front of every buffer (causal left padding)
+    const size_t bytes = (size_t)(maxel + PADF + 128L * 4 * C) * sizeof(float);
+    CK(b_dacA.reserve(bytes)); CK(b_dacB.reserve(bytes)); CK(b_dacC.reserve(bytes));
+    float *bufY = b_dacA.as<float>() + PADF, *bufS = b_dacB.as<float>() + PADF, *bufU = b_dacC.as<float>() + PADF;
+    if (profiling) {
+      for (auto& e : ev) if (!e) CK(hipEventCreate(&e));
+      gemm_events_used = 0;
+      CK(hipEventRecord(ev[0], st));
+    }
+    // ---- PCA inverse (inference.py:228): z = (latent / scale) @ components + mean
+    const int Tp = (int)rup(Tn, 128);
+    CK(b_dmisc.reserve((size_t)Tp * pca_kpad * sizeof(float)));
+    float* x = bufY;
+    if (lat) {
+      CK(launch_pca_prep(lat, b_dmisc.as<float>(), pca_kpad, Tn, cfg.latent_size, pca_kpad, latent_scale, st));
+      GemmArgs g = FG(b_dmisc.as<float>(), pca_kpad, pca_w, pca_kpad, x, C, Tn, C, pca_kpad);
+      g.bias = pca_b;
+      CKI(frun(g, st));
+    } else {
+      CK(hipMemcpyAsync(x, zq, (size_t)Tn * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    // ---- post_module: window-limited causal transformer (autoencoder.py:786-802)
+    const long ldq = 3L * nh * hd;
+    const int Tk = (int)rup(Tn, 32);
+    CK(b_dq.reserve((size_t)(Tp + 128) * ldq * sizeof(float)));
+    CK(b_dscore.reserve((size_t)nh * Tn * Tk * sizeof(float)));
+    CK(b_dvt.reserve((size_t)(nh + 1) * hd * rup(Tn, 64) * sizeof(float) + 128 * rup(Tn, 64) * sizeof(float)));
+    float *xn = bufS, *qkv = b_dq.as<float>(), *sc = b_dscore.as<float>(), *vt = b_dvt.as<float>(), *ao = bufU, *hh = bufS + (long)Tp * C;
+    const int vld = (int)rup(Tn, 64);
+    for (auto& L : dpost) {
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.an, nullptr, st));
+      CKI(frun(FG(xn, C, L.wqkv, C, qkv, ldq, Tn, 3 * nh * hd, C), st));
+      CK(launch_ae_rope(qkv, ldq, Tn, Tn, nh, hd, ae_rope, st));
+      CK(launch_ae_rope(qkv + nh * hd, ldq, Tn, Tn, nh, hd, ae_rope, st));
+      CK(launch_transpose_heads<float>(qkv + 2 * nh * hd, ldq, vt, vld, 0, 1, Tn, nh, hd, st));
+      {
+        GemmArgs g = FG(qkv, ldq, qkv + nh * hd, ldq, sc, Tk, Tn, Tk, hd);
+        g.nbatch = nh; g.nbi = nh; g.a_bi = hd; g.w_bi = hd; g.c_bi = (long)Tn * Tk;
+        g.acc_scale = 1.0f / sqrtf((float)hd);
+        CKI(frun(g, st));
+      }
+      CK(launch_softmax_f32(sc, Tk, Tn, nh, Tn, Tk, nullptr, 0, 1, 1, cfg.dac_post_window, st));
+      {
+        GemmArgs g = FG(sc, Tk, vt, vld, ao, C, Tn, hd, Tk);
+        g.nbatch = nh; g.nbi = nh; g.a_bi = (long)Tn * Tk; g.w_bi = (long)hd * vld; g.c_bi = hd;
+        CKI(frun(g, st));
+      }
+      { GemmArgs g = FG(ao, C, L.wo, nh * hd, x, C, Tn, C, nh * hd); g.colscale = L.ga; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.fn, nullptr, st));
+      { GemmArgs g = FG(xn, C, L.w13, C, hh, ff, Tn, 2 * ff, C); g.swiglu = 1; CKI(frun(g, st)); }
+      { GemmArgs g = FG(hh, ff, L.w2, ff, x, C, Tn, C, ff); g.colscale = L.gf; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+    }
+    CK(launch_norm<float>(NORM_AE_RMS, x, C, bufS, C, Tn, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
+    // ---- quantizer.upsample: [ConvT k=f s=f ; ConvNeXt] (autoencoder.py:427-435, 360-373)
+    float* cur = bufS;      // (rows, C)
+    float* other = bufY;
+    float* third = bufU;
+    long rows = Tn;
+    for (auto& U : dups) {
+      { GemmArgs g = FG(cur, C, U.w, C, other, (long)U.f * C, rows, U.f * C, C); g.bias = U.b; g.vec_mod = C; CKI(frun(g, st)); }
+      rows *= U.f;
+      CK(launch_dwconv_ln(other, C, cur, C, (int)rows, (int)rows, C, U.dw, U.db, U.lnw, U.lnb, 1e-6f, st));
+      { GemmArgs g = FG(cur, C, U.p1w, C, third, 4L * C, rows, 4 * C, C); g.bias = U.p1b; g.act = 2; CKI(frun(g, st)); }
+      { GemmArgs g = FG(third, 4L * C, U.p2w, 4L * C, other, C, rows, C, 4 * C); g.bias = U.p2b; g.colscale = U.gamma; g.res = other; g.ldres = C; CKI(frun(g, st)); }
+      std::swap(cur, other);
+    }
+    // ---- decoder (autoencoder.py:971-998): every conv is a taps-GEMM on channels-last rows
+    float *Y = other, *S = third, *Uu = nullptr;
+    {
+      // conv k7 C -> ch, epilogue writes only snake_{block1}(y)
+      const int ch = cfg.dac_decoder_dim;
+      GemmArgs g = FG(cur, C, dconv0_w, 7L * C, Y, ch, rows, ch, C);
+      g.taps = 7; g.tap_base = -6; g.tap_shift = 1; g.bias = dconv0_b;
+      g.store_main = 0; g.C2 = S; g.snake_alpha = dblocks[0].alpha;
+      CKI(frun(g, st));
+      Uu = cur;
+    }
+    for (size_t bi = 0; bi < dblocks.size(); ++bi) {
+      DacBlock& Bk = dblocks[bi];
+      {
+        // ConvTranspose k=2r s=r as a 2-tap GEMM with N = r*Co; rows of C are r consecutive output steps
+        GemmArgs g = FG(S, Bk.ci, Bk.wt, 2L * Bk.ci, Y, (long)Bk.r * Bk.co, rows, Bk.r * Bk.co, Bk.ci);
+        g.taps = 2; g.tap_base = -1; g.tap_shift = 1; g.bias = Bk.bt; g.vec_mod = Bk.co;
+        g.C2 = Uu; g.snake_alpha = Bk.ru[0].a0;
+        CKI(frun(g, st));
+        rows *= Bk.r;
+        std::swap(S, Uu);   // S now holds snake_{ru0.a0}(y)
+      }
+      const int dil[3] = {1, 3, 9};
+      for (int j = 0; j < 3; ++j) {
+        DacRU& ru = Bk.ru[j];
+        {
+          GemmArgs g = FG(S, Bk.co, ru.w7, 7L * Bk.co, Uu, Bk.co, rows, Bk.co, Bk.co);
+          g.taps = 7; g.tap_base = -6 * dil[j]; g.tap_shift = dil[j]; g.bias = ru.b7;
+          g.store_main = 0; g.C2 = Uu; g.snake_alpha = ru.a1;
+          CKI(frun(g, st));
+        }
+        {
+          const float* next_alpha = j < 2 ? Bk.ru[j + 1].a0 : (bi + 1 < dblocks.size() ? dblocks[bi + 1].alpha : dfinal_alpha);
+          GemmArgs g = FG(Uu, Bk.co, ru.w1, Bk.co, Y, Bk.co, rows, Bk.co, Bk.co);
+          g.bias = ru.b1; g.res = Y; g.ldres = Bk.co;
+          g.store_main = j < 2 ? 1 : 0; g.C2 = S; g.snake_alpha = next_alpha;
+          CKI(frun(g, st));
+        }
+      }
+    }
+    const int cl = cfg.dac_decoder_dim >> cfg.dac_n_rates;
+    CK(launch_conv_out_tanh(S, cl, wav, rows, (int)rows, cl, 7, dout_w, dout_b, st));
+    if (profiling) {
+      CK(hipEventRecord(ev[2], st));
+      CK(hipEventSynchronize(ev[2]));
+      CK(hipEventElapsedTime(&prof.ms_total, ev[0], ev[2]));
+      prof.ms_mod = 0.f; prof.ms_steps = prof.ms_total;
+      collect_gemm_times();
+    }
+    return ECHO_OK;
+  }
+};
+
+__global__ void add_seg_bias_kernel(float* __restrict__ dst, long ld, int rows, int off, int w, const float* __restrict__ bias, long bias_ld,
+                                    int kv_mod) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * w) return;
+  const int r = (int)(i / w), k = (int)(i - (long)r * w);
+  const int kr = kv_mod ? r % kv_mod : r;
+  dst[(long)r * ld + off + k] += bias[(long)kr * bias_ld + k];
+}
+template <typename T>
+int Engine<T>::add_seg_bias(float* biasrows, long ld, int rows, int off, int w, const float* bias, long bias_ld, int kv_mod, hipStream_t st) {
+  hipLaunchKernelGGL(add_seg_bias_kernel, dim3((unsigned)(((long)rows * w + 255) / 256)), dim3(256), 0, st, biasrows, ld, rows, off, w,
+                     bias, bias_ld, kv_mod);
+  CK(hipGetLastError());
+  return ECHO_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+struct echo_ctx {
+  std::unique_ptr<EngineBase> eng;
+};
+
+extern "C" {
+
+int echo_abi_version(void) { return ECHO_ABI_VERSION; }
+
+const char* echo_last_error(echo_ctx* ctx) { return ctx ? ctx->eng->err.c_str() : g_create_error.c_str(); }
+
+int echo_ctx_create(const echo_config* cfg, int device, echo_ctx** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return ECHO_ERR; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libechohip has no CPU fallback)"; return ECHO_ERR; }
+  if (device < 0 || device >= ndev) { g_create_error = "bad device index"; return ECHO_ERR; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return ECHO_ERR; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return ECHO_ERR; }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_create_error = std::string("libechohip is built for gfx950 only, found ") + prop.gcnArchName;
+    return ECHO_ERR;
+  }
+  echo_ctx* c = new echo_ctx();
+  if (cfg->precision == ECHO_BF16) c->eng.reset(new Engine<bf16_t>());
+  else if (cfg->precision == ECHO_F32) c->eng.reset(new Engine<float>());
+  else { delete c; g_create_error = "bad precision"; return ECHO_ERR; }
+  c->eng->cfg = *cfg;
+  c->eng->device = device;
+  *out = c;
+  return ECHO_OK;
+}
+
+void echo_ctx_destroy(echo_ctx* ctx) { delete ctx; }
+
+int echo_load_tensor(echo_ctx* ctx, const char* name, const void* data, int dtype, int ndim, const int64_t* shape, int on_device) {
+  if (!ctx || !name || !data) return ECHO_ERR;
+  EngineBase& E = *ctx->eng;
+  if (dtype != ECHO_F32 && dtype != ECHO_BF16) return E.fail("bad dtype");
+  RawTensor t;
+  t.dtype = dtype;
+  t.numel = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+  const size_t bytes = (size_t)t.numel * (dtype == ECHO_F32 ? 4 : 2);
+  hipError_t e = hipMalloc(&t.d, bytes ? bytes : 4);
+  if (e != hipSuccess) return E.fail(e, "hipMalloc(raw tensor)");
+  e = hipMemcpy(t.d, data, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(t.d); return E.fail(e, "hipMemcpy(raw tensor)"); }
+  auto it = E.raw.find(name);
+  if (it != E.raw.end()) { (void)hipFree(it->second.d); E.raw.erase(it); }
+  E.raw[name] = t;
+  return ECHO_OK;
+}
+
+int echo_finalize_dit(echo_ctx* ctx, void* stream) { return ctx ? ctx->eng->finalize_dit((hipStream_t)stream) : ECHO_ERR; }
+int echo_finalize_dac(echo_ctx* ctx, void* stream) { return ctx ? ctx->eng->finalize_dac((hipStream_t)stream) : ECHO_ERR; }
+int echo_set_rope_table(echo_ctx* ctx, const void* t, int npos) { return ctx ? ctx->eng->set_rope(t, npos) : ECHO_ERR; }
+int echo_set_ae_rope_table(echo_ctx* ctx, const void* t, int npos) { return ctx ? ctx->eng->set_ae_rope(t, npos) : ECHO_ERR; }
+
+int echo_encode_text(echo_ctx* ctx, const int32_t* ids, const float* key_bias, const int32_t* nkeys_host, int B, int Tt, void* stream) {
+  return ctx ? ctx->eng->encode_text(ids, key_bias, nkeys_host, B, Tt, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_encode_speaker(echo_ctx* ctx, const void* latent, const float* key_bias, const int32_t* nkeys_host, int B, int Ts, void* stream) {
+  return ctx ? ctx->eng->encode_speaker(latent, key_bias, nkeys_host, B, Ts, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_encode_latent_prefix(echo_ctx* ctx, const void* latent, int B, int n_latents, long row_stride, void* stream) {
+  return ctx ? ctx->eng->encode_latent(latent, B, n_latents, row_stride, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_scale_speaker_kv(echo_ctx* ctx, float scale, int max_layers, void* stream) {
+  return ctx ? ctx->eng->scale_speaker_kv(scale, max_layers, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dit_forward(echo_ctx* ctx, const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
+                     const int32_t* ton, const int32_t* son, float* v_out, void* stream) {
+  return ctx ? ctx->eng->dit_forward(x, temb, rows, B, S, start_pos, use_latent, ton, son, v_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* x_init, float* latent_out, void* stream) {
+  return ctx ? ctx->eng->sample_euler(p, x_init, latent_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dac_decode(echo_ctx* ctx, const float* latent, int T, float latent_scale, float* wav_out, void* stream) {
+  return ctx ? ctx->eng->dac_decode(latent, T, latent_scale, wav_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, void* stream) {
+  return ctx ? ctx->eng->dac_decode_zq(z, T, wav_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_set_pca(echo_ctx* ctx, const float* w, const float* mean, int on_device, void* stream) {
+  return ctx ? ctx->eng->set_pca(w, mean, on_device, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dac_hop(echo_ctx* ctx) {
+  if (!ctx) return -1;
+  long hop = 1;
+  const echo_config& c = ctx->eng->cfg;
+  for (int i = 0; i < c.dac_n_rates; ++i) hop *= c.dac_rates[i];
+  for (int i = 0; i < c.dac_n_up; ++i) hop *= c.dac_up_factors[i];
+  return (int)hop;
+}
+int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out) {
+  return ctx ? ctx->eng->debug_get_kv(which, layer, k_out, v_out, B_out, T_out) : ECHO_ERR;
+}
+int echo_set_profiling(echo_ctx* ctx, int on) { if (!ctx) return ECHO_ERR; ctx->eng->profiling = on != 0; return ECHO_OK; }
+int echo_get_profile(echo_ctx* ctx, echo_profile* out) { if (!ctx || !out) return ECHO_ERR; *out = ctx->eng->prof; return ECHO_OK; }
+
+// ---- single-kernel entry points
+static thread_local std::string g_op_error;
+static int op_status(hipError_t e) {
+  if (e == hipSuccess) return ECHO_OK;
+  g_create_error = std::string("kernel launch failed: ") + hipGetErrorString(e);
+  return ECHO_ERR;
+}
+
+int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
+  GemmArgs g;
+  gemm_args_init(&g);
+  g.A = d->A; g.W = d->W; g.C = d->C; g.C2 = d->C2; g.M = d->M; g.N = d->N; g.K = d->K; g.Npad = d->Npad;
+  g.lda = d->lda; g.ldw = d->ldw; g.ldc = d->ldc; g.taps = d->taps < 1 ? 1 : d->taps; g.tap_base = d->tap_base; g.tap_shift = d->tap_shift;
+  g.nbatch = d->nbatch < 1 ? 1 : d->nbatch; g.nbi = d->nbi < 1 ? 1 : d->nbi;
+  g.a_bo = d->a_bo; g.a_bi = d->a_bi; g.w_bo = d->w_bo; g.w_bi = d->w_bi; g.c_bo = d->c_bo; g.c_bi = d->c_bi;
+  g.acc_scale = d->acc_scale == 0.0f ? 1.0f : d->acc_scale;
+  g.bias = d->bias; g.bias_bo = d->bias_bo; g.bias_bi = d->bias_bi; g.vec_mod = d->vec_mod; g.div = d->div; g.act = d->act;
+  g.colscale = d->colscale; g.res = d->res; g.ldres = d->ldres; g.res_bo = d->res_bo; g.res_bi = d->res_bi;
+  g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
+  return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
+}
+int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,
+                      int swiglu_half, void* stream) {
+  return op_status(launch_pack_rows(src, sdt, sld, dst, ddt, dld, rows, cols, dst_row0, swiglu_half, (hipStream_t)stream));
+}
+int echo_op_attention_bf16(const echo_attn_desc* d, void* stream) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)d->Q; a.q_ld = d->q_ld; a.q_row_stride = d->q_row_stride;
+  a.O = (bf16_t*)d->O; a.o_ld = d->o_ld; a.o_row_stride = d->o_row_stride;
+  a.G = (const bf16_t*)d->G; a.g_ld = d->g_ld; a.g_row_stride = d->g_row_stride;
+  a.S = d->S; a.H = d->H; a.rows = d->rows; a.nseg = d->nseg; a.causal = d->causal; a.scale = d->scale;
+  for (int s = 0; s < d->nseg && s < 4; ++s) {
+    a.seg[s].K = (const bf16_t*)d->seg[s].K; a.seg[s].k_ld = d->seg[s].k_ld; a.seg[s].k_row_stride = d->seg[s].k_row_stride;
+    a.seg[s].k_head_stride = d->seg[s].k_head_stride;
+    a.seg[s].Vt = (const bf16_t*)d->seg[s].Vt; a.seg[s].vt_ld = d->seg[s].vt_ld; a.seg[s].vt_row_stride = d->seg[s].vt_row_stride;
+    a.seg[s].vt_head_stride = d->seg[s].vt_head_stride;
+    a.seg[s].nkeys = d->seg[s].nkeys; a.seg[s].bias = d->seg[s].bias; a.seg[s].bias_row_stride = d->seg[s].bias_row_stride;
+    a.seg[s].kv_mod = d->seg[s].kv_mod;
+  }
+  return op_status(launch_attention_bf16(a, (hipStream_t)stream));
+}
+int echo_op_norm(int dtype, int mode, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, const void* w0,
+                 const void* w1, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  return op_status(dtype == ECHO_BF16
+                       ? launch_norm<bf16_t>(mode, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, D, eps, (const bf16_t*)w0, (const bf16_t*)w1, st)
+                       : launch_norm<float>(mode, (const float*)x, ldx, (float*)y, ldy, rows, D, eps, (const float*)w0, (const float*)w1, st));
+}
+int echo_op_headnorm_rope(int dtype, void* x, int64_t ldx, int64_t t_stride, int nt, int rows, int S, int H, const void* w,
+                          int64_t w_stride, float eps, int do_norm, int rope_heads, const void* rope, int pos0, int pos_mul, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  return op_status(dtype == ECHO_BF16
+                       ? launch_headnorm_rope_nt<bf16_t>((bf16_t*)x, ldx, t_stride, nt, rows, S, H, (const bf16_t*)w, w_stride, eps, do_norm,
+                                                         rope_heads, (const float2*)rope, pos0, pos_mul, st)
+                       : launch_headnorm_rope_nt<float>((float*)x, ldx, t_stride, nt, rows, S, H, (const float*)w, w_stride, eps, do_norm,
+                                                        rope_heads, (const float2*)rope, pos0, pos_mul, st));
+}
+int echo_op_transpose_heads(int dtype, const void* v, int64_t ldv, void* vt, int64_t vt_ld, int64_t vt_b_stride, int B, int S, int H,
+                            int HD, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  return op_status(dtype == ECHO_BF16
+                       ? launch_transpose_heads<bf16_t>((const bf16_t*)v, ldv, (bf16_t*)vt, vt_ld, vt_b_stride, B, S, H, HD, st)
+                       : launch_transpose_heads<float>((const float*)v, ldv, (float*)vt, vt_ld, vt_b_stride, B, S, H, HD, st));
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+/* libechohip — C ABI of the MI355X-native Echo-TTS hot path.
+ *
+ * The reference (sruckh/echo-tts) is pure Python/PyTorch and has no FFI of its own; the boundary it
+ * offers is its Python call signatures.  Each entry point below replaces the body of
+ * one of those Python functions; the Python host in `echo-tts_amd/` keeps the reference signatures
+ * and calls these through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; echo_last_error() gives the text;
+ *   - all tensor arguments are raw DEVICE pointers owned by the caller unless a parameter says
+ *     "host"; the library never frees caller memory; it owns packed weights, KV caches and
+ *     workspaces inside echo_ctx (grown on demand, never inside the sampler's step loop once warm);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work
+ *     is enqueued on it and nothing synchronises unless stated;
+ *   - dtype codes: ECHO_F32 = 0, ECHO_BF16 = 1.  "T" below is the context's activation type:
+ *     bf16 (production) or f32 (parity mode: fp32 weights, activations and MFMA);
+ *   - one echo_ctx per device, not thread-safe (the reference is single-threaded, one job at a time).
+ */
+#ifndef ECHO_HIP_H
+#define ECHO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECHO_F32 0
+#define ECHO_BF16 1
+#define ECHO_ABI_VERSION 1
+
+typedef struct echo_ctx echo_ctx;
+
+/* Sizes of EchoDiT (reference: inference.py:16-24, model.py:472-559) and of the Fish S1-DAC decode
+ * path (autoencoder.py:1144-1192).  head_dim must be 128 for the DiT and its encoders. */
+typedef struct {
+  int precision;                 /* ECHO_BF16 or ECHO_F32 */
+  int latent_size, model_size, num_layers, num_heads, intermediate_size;
+  float norm_eps;
+  int text_vocab_size, text_model_size, text_num_layers, text_num_heads, text_intermediate_size;
+  int speaker_patch_size, speaker_model_size, speaker_num_layers, speaker_num_heads, speaker_intermediate_size;
+  int timestep_embed_size, adaln_rank;
+  int has_latent_encoder;        /* 0 when the checkpoint was loaded with delete_blockwise_modules (inference.py:28-34) */
+  /* DAC decode path (fp32) */
+  int dac_latent_dim, dac_decoder_dim, dac_n_rates, dac_rates[8];
+  int dac_post_layers, dac_post_heads, dac_post_head_dim, dac_post_ffn, dac_post_window;
+  int dac_n_up, dac_up_factors[4];
+  float dac_norm_eps;
+} echo_config;
+
+int echo_abi_version(void);
+const char* echo_last_error(echo_ctx* ctx);            /* ctx may be NULL: last error of a failed create */
+
+/* handler.py:323-417 `_load_models` / inference.py:14-47,56-76: context + weights */
+int echo_ctx_create(const echo_config* cfg, int device, echo_ctx** out);
+void echo_ctx_destroy(echo_ctx* ctx);
+
+/* Register one checkpoint tensor under its reference state-dict name (SURVEY.md §A.5 for EchoDiT;
+ * INTEGRATION.md lists the DAC names, which are the reference names with weight-norm folded and the
+ * conv kernels reshaped to GEMM form by the Python loader).  `data` may be a host or a device pointer. */
+int echo_load_tensor(echo_ctx* ctx, const char* name, const void* data, int dtype, int ndim, const int64_t* shape,
+                     int data_on_device);
+int echo_finalize_dit(echo_ctx* ctx, void* stream);    /* pack EchoDiT weights for the kernels, drop the raw copies */
+int echo_finalize_dac(echo_ctx* ctx, void* stream);
+
+/* Position tables computed by the host with the reference's own expressions (exactness for free):
+ * rope: (npos, 64) float2 = (cos, sin) of model.py:9-14 for head_dim 128;
+ * ae_rope: (npos, head_dim/2, 2) fp32 copy of the bf16 cache of autoencoder.py:805-813. */
+int echo_set_rope_table(echo_ctx* ctx, const void* table_dev, int npos);
+int echo_set_ae_rope_table(echo_ctx* ctx, const void* table_dev, int npos);
+
+/* model.py:606-613 EchoDiT.get_kv_cache_text.  ids (B,Tt) int32; key_bias: NULL when every mask is a
+ * prefix, else (B,Tt) f32 additive 0/-inf; nkeys_host[b] = 1 + index of the last attended token. */
+int echo_encode_text(echo_ctx* ctx, const int32_t* ids, const float* key_bias, const int32_t* nkeys_host, int B, int Tt,
+                     void* stream);
+/* model.py:615-621 get_kv_cache_speaker.  latent (B,Ts,latent) of T; masks are over the Ts/patch keys. */
+int echo_encode_speaker(echo_ctx* ctx, const void* latent, const float* key_bias, const int32_t* nkeys_host, int B, int Ts,
+                        void* stream);
+/* model.py:623-636 get_kv_cache_latent for the first n_latents (multiple of patch) prefix latents. */
+int echo_encode_latent_prefix(echo_ctx* ctx, const void* latent, int B, int n_latents, long row_stride_elems, void* stream);
+/* inference.py:408-414 _multiply_kv_cache on the speaker cache (K and V of layers < max_layers) */
+int echo_scale_speaker_kv(echo_ctx* ctx, float scale, int max_layers, void* stream);
+
+/* model.py:563-604 EchoDiT.forward for `rows` = R*B rows that share one timestep.
+ * x (rows*S, latent) of T; temb (1, timestep_embed) of T (model.py:27-43 evaluated by the host);
+ * row r uses text/speaker KV of batch item r % B; row_text_on/row_spk_on (host, rows) switch the
+ * segments per row (the CFG "uncond" rows); v_out (rows*S, latent) fp32. */
+int echo_dit_forward(echo_ctx* ctx, const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
+                     const int32_t* row_text_on, const int32_t* row_spk_on, float* v_out, void* stream);
+
+typedef struct {
+  int has_cfg;                   /* inference.py:484 */
+  float dt;                      /* fp32 (t_next - t), inference.py:515 */
+  int rescale;                   /* inference.py:507-508, coefficients of inference.py:421-423 evaluated by the host */
+  float r_inv1mt, r_ratio, r_1mt;
+  int kv_unscale_after;          /* inference.py:511-513 */
+} echo_step;
+
+typedef struct {
+  int B, S, num_steps;
+  int start_pos, use_latent;     /* blockwise: inference_blockwise.py:91-94 */
+  float cfg_scale_text, cfg_scale_speaker;
+  float init_scale;              /* truncation_factor or 1 (inference.py:478-479) */
+  float kv_scale; int kv_max_layers;   /* used by kv_unscale_after steps: multiply by 1/kv_scale */
+  const echo_step* steps;        /* host, num_steps entries */
+  const void* temb;              /* device, (num_steps, timestep_embed) of T */
+} echo_sampler_params;
+
+/* inference.py:427-517 sample_euler_cfg_independent_guidances, from the noise draw on.
+ * x_init (B,S,latent) fp32 noise (the host draws it exactly like inference.py:457,477);
+ * latent_out (B,S,latent) fp32.  Text/speaker(/latent) KV must have been encoded on this ctx. */
+int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* x_init, float* latent_out, void* stream);
+
+/* inference.py:226-229 ae_decode -> autoencoder.py:1128-1132 DAC.decode_zq, one batch item:
+ * latent (T, latent_size) fp32 -> wav (T * hop) fp32. */
+int echo_dac_decode(echo_ctx* ctx, const float* latent, int T, float latent_scale, float* wav_out, void* stream);
+/* autoencoder.py:1128-1132 DAC.decode_zq alone: z (T, dac_latent_dim) fp32 CHANNELS-LAST (= z_q[b].T) -> wav (T * hop). */
+int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, void* stream);
+/* inference.py:86-99 PCAState: w = pca_components transposed, (dac_latent_dim, latent_size) row-major fp32; mean (dac_latent_dim). */
+int echo_set_pca(echo_ctx* ctx, const float* w, const float* mean, int on_device, void* stream);
+int echo_dac_hop(echo_ctx* ctx);
+
+/* ---- single-kernel entry points (unit tests and micro-benchmarks; same kernels the engine launches) ---- */
+typedef struct {
+  const void* A; const void* W; void* C; void* C2;
+  int M, N, K, Npad; int64_t lda, ldw, ldc;
+  int taps, tap_base, tap_shift;
+  int nbatch, nbi; int64_t a_bo, a_bi, w_bo, w_bi, c_bo, c_bi;
+  float acc_scale;
+  const void* bias; int64_t bias_bo, bias_bi; int vec_mod;
+  float div; int act;
+  const void* colscale;
+  const void* res; int64_t ldres, res_bo, res_bi;
+  const void* snake_alpha;
+  int store_main, swiglu;
+} echo_gemm_desc;
+int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
+int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,
+                      int cols, int dst_row0, int swiglu_half, void* stream);
+
+typedef struct {
+  const void* K; int64_t k_ld, k_row_stride, k_head_stride;
+  const void* Vt; int64_t vt_ld, vt_row_stride, vt_head_stride;
+  const int32_t* nkeys; const float* bias; int64_t bias_row_stride; int kv_mod;
+} echo_attn_seg;
+typedef struct {
+  const void* Q; int64_t q_ld, q_row_stride;
+  void* O; int64_t o_ld, o_row_stride;
+  const void* G; int64_t g_ld, g_row_stride;
+  int S, H, rows, nseg; echo_attn_seg seg[4]; int causal; float scale;
+} echo_attn_desc;
+int echo_op_attention_bf16(const echo_attn_desc* d, void* stream);
+
+int echo_op_norm(int dtype, int mode, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps,
+                 const void* w0, const void* w1, void* stream);
+int echo_op_headnorm_rope(int dtype, void* x, int64_t ldx, int64_t t_stride, int nt, int rows, int S, int H, const void* w,
+                          int64_t w_stride, float eps, int do_norm, int rope_heads, const void* rope, int pos0, int pos_mul,
+                          void* stream);
+int echo_op_transpose_heads(int dtype, const void* v, int64_t ldv, void* vt, int64_t vt_ld, int64_t vt_b_stride, int B, int S,
+                            int H, int HD, void* stream);
+
+/* test hook: copy one DiT layer's cached K and V (which: 0 text, 1 speaker, 2 latent) as fp32 (B, T, model_size);
+ * K is post-k_norm(/RoPE), V as projected.  Synchronous.  *B_out / *T_out receive the cache geometry. */
+int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out);
+
+/* timing of the engine's phases, filled by the last echo_sample_euler / echo_dac_decode when
+ * echo_set_profiling(ctx, 1) was called (HIP events on the caller's stream; adds synchronisation) */
+typedef struct {
+  float ms_mod, ms_steps, ms_total;
+  float ms_gemm_sum; int n_gemm;   /* sum / count of gemm_nt launch durations of the last profiled run */
+} echo_profile;
+int echo_set_profiling(echo_ctx* ctx, int on);
+int echo_get_profile(echo_ctx* ctx, echo_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

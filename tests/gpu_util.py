@@ -1,0 +1,84 @@
+"""Helpers for the -m gpu tests: call libechohip's single-kernel entry points on torch (ROCm) tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+import echo_tts_amd  # noqa: F401  (package alias)
+from echo_tts_amd import _lib as L
+
+DEV = "cuda:0"
+
+
+def lib():
+    return L.load_library()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def code(t: torch.Tensor) -> int:
+    return L.ECHO_BF16 if t.dtype == torch.bfloat16 else L.ECHO_F32
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    n = w.shape[0]
+    npad = (n + mult - 1) // mult * mult
+    out = torch.zeros((npad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[:n] = w
+    return out
+
+
+def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
+         nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
+         vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
+         swiglu=0, Npad=None, a_offset_elems=0):
+    d = L.EchoGemmDesc()
+    es = A.element_size()
+    d.A = A.data_ptr() + a_offset_elems * es
+    d.W, d.C, d.C2 = W.data_ptr(), C_out.data_ptr(), ptr(C2)
+    d.M, d.N, d.K = M, N, K
+    d.Npad = Npad if Npad is not None else (N + 127) // 128 * 128
+    d.lda, d.ldw, d.ldc = lda, ldw, ldc
+    d.taps, d.tap_base, d.tap_shift = taps, tap_base, tap_shift
+    d.nbatch, d.nbi = nbatch, nbi
+    d.a_bo, d.a_bi, d.w_bo, d.w_bi, d.c_bo, d.c_bi = a_bo, a_bi, w_bo, w_bi, c_bo, c_bi
+    d.acc_scale = acc_scale
+    d.bias, d.bias_bo, d.bias_bi, d.vec_mod = ptr(bias), bias_bo, bias_bi, vec_mod
+    d.div, d.act = div, act
+    d.colscale = ptr(colscale)
+    d.res, d.ldres, d.res_bo, d.res_bi = ptr(res), ldres, res_bo, res_bi
+    d.snake_alpha = ptr(snake_alpha)
+    d.store_main, d.swiglu = store_main, swiglu
+    L.check(lib().echo_op_gemm(code(A), C.byref(d), stream()))
+
+
+def pack_swiglu(w1: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """[16 rows of w1 | 16 rows of w3] blocks, the layout gemm.hip's SWIGLU epilogue expects."""
+    f, k = w1.shape
+    out = torch.zeros(((2 * f + 127) // 128 * 128, k), dtype=w1.dtype, device=w1.device)
+    for half, w in ((0, w1), (1, w3)):
+        L.check(lib().echo_op_pack_rows(w.data_ptr(), code(w), k, out.data_ptr(), code(out), k, f, k, 0, half, stream()))
+    return out
+
+
+def bf16_close(out: torch.Tensor, ref: torch.Tensor, ulps: float = 2.0, atol: float = 0.0, frac_exact: float = 0.0):
+    """out, ref as fp32 values of bf16 numbers: |out-ref| <= ulps * 2^-8 * |ref| + atol everywhere."""
+    o, r = out.float(), ref.float()
+    err = (o - r).abs()
+    tol = ulps * (2.0 ** -8) * r.abs() + atol
+    bad = err > tol
+    assert not bool(bad.any()), f"{int(bad.sum())} / {bad.numel()} elements off; max err {float(err.max()):.4g}, worst ref {float(r[bad].abs().max()):.4g}"
+    if frac_exact:
+        fe = float((o == r).float().mean())
+        assert fe >= frac_exact, f"only {fe:.4f} of elements match the reference rounding exactly"
+
+
+def rms(x: torch.Tensor) -> float:
+    return float(x.float().pow(2).mean().sqrt())

@@ -1,0 +1,289 @@
+"""GPU: each hand-written HIP kernel against a plain PyTorch fp32/fp64 evaluation of the same op,
+called through the C ABI (echo_op_*).  bf16 kernels are compared with the fp32 result rounded at
+the reference's rounding points; fp32 kernels with an fp64 evaluation."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as U  # noqa: E402
+from echo_tts_amd import _lib as L  # noqa: E402
+
+DEV = U.DEV
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (640, 384, 2048), (37, 80, 128), (1920, 256, 512)])
+def test_gemm_bf16_plain(M, N, K):
+    A = rnd(M, K, dtype=torch.bfloat16)
+    W = U.pad_rows(rnd(N, K, dtype=torch.bfloat16, seed=1))
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N)
+    ref = (A.float() @ W[:N].float().T).bfloat16()
+    U.bf16_close(out, ref, ulps=1.01, atol=1e-3, frac_exact=0.98)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 256, 160), (77, 96, 96), (640, 1024, 1024)])
+def test_gemm_f32_matches_fp64(M, N, K):
+    A = rnd(M, K)
+    W = U.pad_rows(rnd(N, K, seed=1))
+    out = torch.zeros((M, N), device=DEV)
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N)
+    ref = (A.double() @ W[:N].double().T)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-5 * math.sqrt(K), err
+
+
+def test_gemm_bf16_epilogue_chain():
+    """bias -> round -> /6 -> silu -> colscale -> +res, each rounded to bf16 (model.py:461-462, 385-388)."""
+    M, N, K = 300, 256, 128
+    A, W = rnd(M, K, dtype=torch.bfloat16), U.pad_rows(rnd(N, K, dtype=torch.bfloat16, seed=1))
+    bias, cs = rnd(N, dtype=torch.bfloat16, seed=2), rnd(N, dtype=torch.bfloat16, seed=3)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=4)
+    out = res.clone()
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias, div=6.0, act=1, colscale=cs, res=out, ldres=N)
+    y = (A.float() @ W[:N].float().T + bias.float()).bfloat16()
+    y = (y.float() / 6.0).bfloat16()
+    y = torch.nn.functional.silu(y.float()).bfloat16()
+    y = (y.float() * cs.float()).bfloat16()
+    y = (y.float() + res.float()).bfloat16()
+    U.bf16_close(out, y, ulps=2.0, atol=2e-3)
+
+
+def test_gemm_bf16_swiglu():
+    M, F, K = 256, 192, 256
+    A = rnd(M, K, dtype=torch.bfloat16)
+    w1, w3 = rnd(F, K, dtype=torch.bfloat16, seed=1, scale=0.1), rnd(F, K, dtype=torch.bfloat16, seed=2, scale=0.1)
+    Wp = U.pack_swiglu(w1, w3)
+    out = torch.zeros((M, F), dtype=torch.bfloat16, device=DEV)
+    U.gemm(A, Wp, out, M=M, N=2 * F, K=K, lda=K, ldw=K, ldc=F, swiglu=1, Npad=Wp.shape[0])
+    a = (A.float() @ w1.float().T).bfloat16()
+    b = (A.float() @ w3.float().T).bfloat16()
+    ref = (torch.nn.functional.silu(a.float()).bfloat16().float() * b.float()).bfloat16()
+    U.bf16_close(out, ref, ulps=2.0, atol=2e-3)
+
+
+def test_gemm_f32_batched_two_level():
+    """z -> (zo, zi) strides, as used for the AdaLN low-rank refinements and per-head attention GEMMs."""
+    nbo, nbi, M, N, K = 3, 2, 70, 64, 64
+    A = rnd(nbo, nbi, M, K)
+    W = rnd(nbo, nbi, 128, K, seed=1)
+    out = torch.zeros((nbo, nbi, M, N), device=DEV)
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, nbatch=nbo * nbi, nbi=nbi, a_bo=nbi * M * K, a_bi=M * K,
+           w_bo=nbi * 128 * K, w_bi=128 * K, c_bo=nbi * M * N, c_bi=M * N, acc_scale=0.5)
+    ref = 0.5 * torch.einsum("abmk,abnk->abmn", A.double(), W[:, :, :N].double())
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("k,dil", [(7, 1), (7, 3), (7, 9), (1, 1)])
+def test_gemm_f32_causal_conv_taps(k, dil):
+    """taps loop == causal Conv1d on channels-last rows (autoencoder.py:264-289), incl. Snake second output."""
+    T, Ci, Co = 300, 64, 96
+    x = rnd(1, Ci, T, scale=1.0)
+    w = rnd(Co, Ci, k, seed=1, scale=0.1)
+    b = rnd(Co, seed=2, scale=0.1)
+    alpha = 1.0 + 0.2 * rnd(Co, seed=3)
+    pad = (k - 1) * dil
+    ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double(), (pad, 0)), w.double(), b.double(), dilation=dil)
+    ref_cl = ref[0].T  # (T, Co)
+    xcl = torch.zeros((64 + T, Ci), device=DEV)
+    xcl[64:] = x[0].T
+    Wg = U.pad_rows(w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous())
+    out = torch.zeros((T, Co), device=DEV)
+    out2 = torch.zeros((T, Co), device=DEV)
+    U.gemm(xcl, Wg, out, C2=out2, M=T, N=Co, K=Ci, lda=Ci, ldw=k * Ci, ldc=Co, taps=k, tap_base=-(k - 1) * dil, tap_shift=dil,
+           bias=b, snake_alpha=alpha, a_offset_elems=64 * Ci)
+    assert (out.double() - ref_cl).abs().max().item() < 1e-4
+    sref = ref_cl + (1.0 / (alpha.double() + 1e-9)) * torch.sin(alpha.double() * ref_cl) ** 2
+    assert (out2.double() - sref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("r", [2, 8])
+def test_gemm_f32_causal_conv_transpose(r):
+    """2-tap GEMM with N = r*Co == causal ConvTranspose1d k=2r, stride r (autoencoder.py:300-316)."""
+    from echo_tts_amd.autoencoder import _convT_as_gemm
+    T, Ci, Co = 200, 64, 32
+    x = rnd(1, Ci, T)
+    w = rnd(Ci, Co, 2 * r, seed=1, scale=0.1)
+    b = rnd(Co, seed=2, scale=0.1)
+    ref = torch.nn.functional.conv_transpose1d(x.double(), w.double(), b.double(), stride=r)[..., : T * r]
+    ref_cl = ref[0].T  # (T*r, Co)
+    xcl = torch.zeros((64 + T, Ci), device=DEV)
+    xcl[64:] = x[0].T
+    Wg = U.pad_rows(_convT_as_gemm(w, r))
+    out = torch.zeros((T * r, Co), device=DEV)
+    U.gemm(xcl, Wg, out, M=T, N=r * Co, K=Ci, lda=Ci, ldw=2 * Ci, ldc=r * Co, taps=2, tap_base=-1, tap_shift=1, bias=b,
+           vec_mod=Co, a_offset_elems=64 * Ci)
+    assert (out.double() - ref_cl).abs().max().item() < 1e-4
+
+
+# --------------------------------------------------------------------------- attention
+def _ref_attention(q, segs, scale, causal, gate):
+    """q (R,S,H,128) fp32; segs: list of (K (R,Lk,H,128), V, mask (R,Lk) bool).  fp32 softmax attention."""
+    K = torch.cat([s[0] for s in segs], 1)
+    V = torch.cat([s[1] for s in segs], 1)
+    m = torch.cat([s[2] for s in segs], 1)[:, None, None]
+    if causal:
+        S = q.shape[1]
+        m = m & torch.tril(torch.ones(S, K.shape[1], dtype=torch.bool, device=q.device))[None, None]
+    o = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2), attn_mask=m,
+                                                         scale=scale).transpose(1, 2)
+    o = o.bfloat16().float()
+    if gate is not None:
+        o = (o * torch.sigmoid(gate.float()).bfloat16().float()).bfloat16().float()
+    return o
+
+
+def _to_vt(v, pitch):
+    """(Rk, Lk, H, 128) -> (Rk, H, 128, pitch) zero padded."""
+    Rk, Lk, H, D = v.shape
+    vt = torch.zeros((Rk, H, D, pitch), dtype=v.dtype, device=v.device)
+    vt[..., :Lk] = v.permute(0, 2, 3, 1)
+    return vt.contiguous()
+
+
+@pytest.mark.parametrize("S,Lt,Ls,use_bias", [(200, 70, 33, False), (128, 64, 128, True), (640, 436, 640, False)])
+def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias):
+    R, H = 3, 2
+    q = rnd(R, S, H, 128, dtype=torch.bfloat16)
+    k_self, v_self = rnd(R, S, H, 128, dtype=torch.bfloat16, seed=1), rnd(R, S, H, 128, dtype=torch.bfloat16, seed=2)
+    k_t, v_t = rnd(1, Lt, H, 128, dtype=torch.bfloat16, seed=3), rnd(1, Lt, H, 128, dtype=torch.bfloat16, seed=4)
+    k_s, v_s = rnd(1, Ls, H, 128, dtype=torch.bfloat16, seed=5), rnd(1, Ls, H, 128, dtype=torch.bfloat16, seed=6)
+    gate = rnd(R, S, H * 128, dtype=torch.bfloat16, seed=7)
+    # CFG rows: row 1 drops text, row 2 drops speaker; text uses a shorter valid prefix
+    nt = Lt - 5
+    tmask = torch.zeros((R, Lt), dtype=torch.bool, device=DEV)
+    tmask[0, :nt] = True
+    tmask[2, :nt] = True
+    if use_bias:
+        tmask[0, 3] = False
+        tmask[2, 3] = False
+    smask = torch.ones((R, Ls), dtype=torch.bool, device=DEV)
+    smask[2] = False
+    ones = torch.ones((R, S), dtype=torch.bool, device=DEV)
+    ref = _ref_attention(q.float(), [(k_self.float(), v_self.float(), ones),
+                                     (k_t.float().expand(R, -1, -1, -1), v_t.float().expand(R, -1, -1, -1), tmask),
+                                     (k_s.float().expand(R, -1, -1, -1), v_s.float().expand(R, -1, -1, -1), smask)],
+                         1 / math.sqrt(128), False, gate.view(R, S, H, 128))
+    out = torch.zeros((R, S, H * 128), dtype=torch.bfloat16, device=DEV)
+    pS, pT, pSp = (S + 63) // 64 * 64, (Lt + 63) // 64 * 64, (Ls + 63) // 64 * 64
+    vt_self, vt_t, vt_s = _to_vt(v_self, pS), _to_vt(v_t, pT), _to_vt(v_s, pSp)
+    nk = torch.tensor([[S, S, S], [nt, 0, nt], [Ls, Ls, 0]], dtype=torch.int32, device=DEV)
+    bias = None
+    if use_bias:
+        bias = torch.zeros((1, Lt), device=DEV)
+        bias[0, 3] = float("-inf")
+    d = L.EchoAttnDesc()
+    d.Q, d.q_ld, d.q_row_stride = q.data_ptr(), H * 128, S * H * 128
+    d.O, d.o_ld, d.o_row_stride = out.data_ptr(), H * 128, S * H * 128
+    d.G, d.g_ld, d.g_row_stride = gate.data_ptr(), H * 128, S * H * 128
+    d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 3, 0, 1 / math.sqrt(128)
+    for i, (kk, vt, pitch, shared) in enumerate(((k_self, vt_self, pS, False), (k_t, vt_t, pT, True), (k_s, vt_s, pSp, True))):
+        sg = d.seg[i]
+        sg.K, sg.k_ld, sg.k_head_stride = kk.data_ptr(), H * 128, 128
+        sg.k_row_stride = 0 if shared else kk.shape[1] * H * 128
+        sg.Vt, sg.vt_ld, sg.vt_head_stride = vt.data_ptr(), pitch, 128 * pitch
+        sg.vt_row_stride = 0 if shared else H * 128 * pitch
+        sg.nkeys = nk[i].data_ptr()
+        sg.kv_mod = 1 if shared else 0
+        if i == 1 and bias is not None:
+            sg.bias, sg.bias_row_stride = bias.data_ptr(), Lt
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    err = (out.float() - ref.reshape(R, S, H * 128)).abs()
+    assert float(err.max()) < 3e-2, float(err.max())
+    assert float(err.mean()) < 2e-3, float(err.mean())
+
+
+@pytest.mark.parametrize("S", [100, 256])
+def test_attention_bf16_causal_self(S):
+    R, H = 2, 3
+    q, k, v = (rnd(R, S, H, 128, dtype=torch.bfloat16, seed=i) for i in range(3))
+    ones = torch.ones((R, S), dtype=torch.bool, device=DEV)
+    ref = _ref_attention(q.float(), [(k.float(), v.float(), ones)], 1 / math.sqrt(128), True, None)
+    out = torch.zeros((R, S, H * 128), dtype=torch.bfloat16, device=DEV)
+    pS = (S + 63) // 64 * 64
+    vt = _to_vt(v, pS)
+    nk = torch.full((R,), S, dtype=torch.int32, device=DEV)
+    d = L.EchoAttnDesc()
+    d.Q, d.q_ld, d.q_row_stride = q.data_ptr(), H * 128, S * H * 128
+    d.O, d.o_ld, d.o_row_stride = out.data_ptr(), H * 128, S * H * 128
+    d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 1, 1, 1 / math.sqrt(128)
+    sg = d.seg[0]
+    sg.K, sg.k_ld, sg.k_head_stride, sg.k_row_stride = k.data_ptr(), H * 128, 128, S * H * 128
+    sg.Vt, sg.vt_ld, sg.vt_head_stride, sg.vt_row_stride = vt.data_ptr(), pS, 128 * pS, H * 128 * pS
+    sg.nkeys = nk.data_ptr()
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    err = (out.float() - ref.reshape(R, S, H * 128)).abs()
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3, (float(err.max()), float(err.mean()))
+
+
+# --------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("D", [256, 1280, 2048])
+def test_norm_modes(dt, D):
+    rows = 37
+    x = rnd(rows, D, dtype=dt)
+    w0, w1 = (1 + 0.1 * rnd(D, seed=1)).to(dt), (0.1 * rnd(D, seed=2)).to(dt)
+    xf = x.float()
+    rs = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    refs = {
+        0: (xf * rs * w0.float() + w1.float()).to(dt),
+        1: (xf * rs * w0.float()).to(dt),
+        2: ((xf * rs).to(dt) * w0).to(dt),
+        3: torch.nn.functional.layer_norm(xf, (D,), w0.float(), w1.float(), 1e-5).to(dt),
+    }
+    for mode, ref in refs.items():
+        y = torch.zeros_like(x)
+        L.check(U.lib().echo_op_norm(U.code(x), mode, x.data_ptr(), D, y.data_ptr(), D, rows, D, 1e-5, w0.data_ptr(), w1.data_ptr(),
+                                     U.stream()))
+        if dt == torch.bfloat16:
+            U.bf16_close(y, ref, ulps=1.01, atol=1e-3)
+        else:
+            assert (y - ref).abs().max().item() < 2e-5, mode
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_headnorm_rope_half_heads(dt):
+    """q_norm/k_norm + RoPE on heads [0, H/2) at positions start_pos + s (model.py:199-232)."""
+    from oracle import echo_ref as R
+    rows, S, H, start = 2, 50, 4, 7
+    D = H * 128
+    x = rnd(rows * S, 2 * D, dtype=dt)           # [q | k] side by side, like the QKVG buffer
+    w = (1 + 0.1 * rnd(2, H, 128, seed=1)).to(dt)
+    fc = R.rope_table(128, start + S)
+    ref = []
+    for ti in range(2):
+        xt = x[:, ti * D:(ti + 1) * D].reshape(rows, S, H, 128).cpu()
+        xn = R.rms_norm(xt, w[ti].cpu(), 1e-5)
+        ref.append(R.rotate_first_half_of_heads(xn, fc[start:start + S]).reshape(rows * S, D))
+    ref = torch.cat(ref, 1)
+    table = torch.view_as_real(fc).contiguous().to(DEV)
+    L.check(U.lib().echo_op_headnorm_rope(U.code(x), x.data_ptr(), 2 * D, D, 2, rows * S, S, H, w.data_ptr(), D, 1e-5, 1, H // 2,
+                                          table.data_ptr(), start, 1, U.stream()))
+    if dt == torch.bfloat16:
+        U.bf16_close(x.cpu(), ref, ulps=1.01, atol=1e-3)
+    else:
+        assert (x.cpu() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dt,HD", [(torch.bfloat16, 128), (torch.float32, 128), (torch.float32, 64)])
+def test_transpose_heads(dt, HD):
+    B, S, H = 2, 150, 3
+    v = rnd(B * S, H * HD + 16, dtype=dt)
+    pitch = (S + 63) // 64 * 64
+    vt = torch.full((B, H, HD, pitch), 5.0, dtype=dt, device=DEV)
+    L.check(U.lib().echo_op_transpose_heads(U.code(v), v.data_ptr(), H * HD + 16, vt.data_ptr(), pitch, H * HD * pitch, B, S, H, HD,
+                                            U.stream()))
+    ref = v[:, :H * HD].reshape(B, S, H, HD).permute(0, 2, 3, 1)
+    assert torch.equal(vt[..., :S], ref)
+    assert bool((vt[..., S:] == 0).all())

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the product package (no GPU, no compute through the HIP library)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import echo_tts_amd as E
+from echo_tts_amd import _lib as L
+from echo_tts_amd import inference as inf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.load_library()
+    header = open(os.path.join(ROOT, "include", "echo_hip.h"), encoding="utf-8").read()
+    declared = set(re.findall(r"\b(echo_[a-z0-9_]+)\s*\(", header)) - {"echo_ctx"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/echo_hip.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.echo_abi_version() == L.ABI_VERSION
+
+
+def test_struct_sizes_match_the_header():
+    # sizes computed from the C declarations (ints / floats / pointers / int64), guarding field drift
+    assert ctypes.sizeof(L.EchoStep) == 7 * 4
+    assert ctypes.sizeof(L.EchoConfig) == 4 * (1 + 5 + 1 + 5 + 5 + 2 + 1 + 3 + 8 + 5 + 1 + 4 + 1)
+    assert ctypes.sizeof(L.EchoSamplerParams) == 10 * 4 + 2 * 8
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        E.EchoDiT(E.EchoDiTConfig(), {}, device="cpu")
+    cfg = L.EchoConfig()
+    ctx = ctypes.c_void_p()
+    assert L.load_library().echo_ctx_create(ctypes.byref(cfg), 0, ctypes.byref(ctx)) != 0
+    assert b"no HIP device" in L.load_library().echo_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "echo-tts_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn), encoding="utf-8").read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{fn} mentions the oracle"
+
+
+def test_tokenizer_and_masks_kat(golden):
+    host = golden["__meta__"]["host"]
+    for case in host["tokenizer"]:
+        ids, norm = inf.tokenizer_encode(case["text"], return_normalized_text=True)
+        assert ids.tolist() == case["ids"]
+        assert norm == case["normalized"]
+    c0, c1 = host["ids_mask"]
+    ids, mask, norm = inf.get_text_input_ids_and_mask(c0["texts"], max_length=768, return_normalized_text=True, pad_to_max=False)
+    assert list(ids.shape) == c0["shape"] == [2, 768] and ids.dtype == torch.int32 and mask.dtype == torch.bool
+    assert mask.sum(1).tolist() == c0["valid"] and ids[:, :24].tolist() == c0["first"] and norm == c0["normalized"]
+    ids, mask = inf.get_text_input_ids_and_mask(c1["texts"], max_length=None)
+    assert list(ids.shape) == c1["shape"] and mask.sum(1).tolist() == c1["valid"] and ids[:, :24].tolist() == c1["first"]
+
+
+def test_chunk_text_kat(golden):
+    for case in golden["__meta__"]["host"]["chunk_text"]:
+        assert inf.chunk_text(case["text"], case["max_chars"]) == case["chunks"]
+    with pytest.raises(ValueError):
+        inf.chunk_text("abc", 0)
+
+
+def test_flattening_point_kat(golden):
+    want = golden["__meta__"]["host"]["flattening"]
+    assert [inf.find_flattening_point(golden[f"flat.{i}"]) for i in range(3)] == want
+    lat = torch.zeros((30, 80))
+    assert inf.find_flattening_point(lat) == 0
+    audio = torch.zeros((1, 1, 30 * 2048))
+    assert inf.crop_audio_to_flattening_point(audio, torch.ones((30, 80)) * 3).shape[-1] == 30 * 2048
+
+
+def test_schedule_matches_reference_facts():
+    class M:  # build_schedule only needs dtype and the embed size
+        dtype = torch.bfloat16
+        config = E.EchoDiTConfig()
+    steps, temb = inf.build_schedule(M, 40, 0.5, 1.0, None, None, None, None)
+    assert sum(s.has_cfg for s in steps) == 20                      # 20 CFG steps of 40
+    assert temb.shape == (40, 512) and temb.dtype == torch.bfloat16
+    assert abs(sum(s.dt for s in steps) + 0.999) < 1e-6
+    # bf16(0.999) == 1.0: the first embedding equals the embedding of t = 1
+    from echo_tts_amd.model import timestep_embedding
+    assert torch.equal(temb[0], timestep_embedding(torch.ones(1).bfloat16(), 512)[0])
+    steps, _ = inf.build_schedule(M, 6, 0.4, 0.9, 1.2, 3.0, 1.5, 0.6)
+    assert [s.kv_unscale_after for s in steps].count(1) == 1 and all(s.rescale for s in steps)
+
+
+def test_conv_weight_reshapes_are_consistent():
+    """The GEMM forms used by the HIP taps loop equal the convolutions they replace (checked with torch on CPU)."""
+    from echo_tts_amd.autoencoder import _conv_as_gemm, _convT_as_gemm
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 6, 20), generator=g, dtype=torch.float64)
+    w = torch.randn((5, 6, 7), generator=g, dtype=torch.float64)
+    for dil in (1, 3):
+        ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x, (6 * dil, 0)), w, dilation=dil)[0].T
+        xp = torch.cat([torch.zeros((6 * dil, 6), dtype=torch.float64), x[0].T])
+        rows = torch.stack([torch.cat([xp[t + j * dil] for j in range(7)]) for t in range(20)])
+        assert torch.allclose(rows @ _conv_as_gemm(w).T, ref)
+    wt = torch.randn((6, 4, 8), generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv_transpose1d(x, wt, stride=4)[0, :, :80].T
+    xp = torch.cat([torch.zeros((1, 6), dtype=torch.float64), x[0].T])
+    rows = torch.stack([torch.cat([xp[q], xp[q + 1]]) for q in range(20)])
+    out = (rows @ _convT_as_gemm(wt, 4).T).reshape(80, 4)
+    assert torch.allclose(out, ref)
