@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the Echo-TTS hot path on MI355X: BASELINE.json config C2.
+
+One "step" = one utterance through the whole hot path on one GPU: text + speaker KV encode,
+sample_euler_cfg_independent_guidances (S=640, 40 Euler steps, CFG text 3.0 / speaker 8.0 on
+t in [0.5, 1] -> 20 three-row + 20 one-row EchoDiT forwards, bf16) and ae_decode (Fish S1-DAC, fp32)
+-> 640 * 2048 / 44100 = 29.72 audio-seconds.  Inputs are resident in HBM before the timed region.
+Weights are seeded random tensors of the exact architecture (the checkpoints are gated), text is a
+synthetic 436-token prompt padded to 768 like sample_pipeline does, the speaker reference is a
+synthetic (1, 2560, 80) latent.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
+utterances); the only collective in the job is the start-up broadcast of the frozen weights from
+rank 0 over RCCL, plus the barriers / max-reduction that bracket the timed region.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+S, STEPS, TT, TVALID, TS = 640, 40, 768, 436, 2560
+SAMPLER = dict(num_steps=STEPS, cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_min_t=0.5, cfg_max_t=1.0, truncation_factor=None,
+               rescale_k=None, rescale_sigma=None, speaker_kv_scale=None, speaker_kv_max_layers=None, speaker_kv_min_t=None,
+               sequence_length=S)
+AUDIO_S = S * 2048 / 44100.0
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def dit_gemm_flops() -> float:
+    """Algorithmic FLOPs of the gemm_nt launches inside one sampler run: 80 row-forwards of
+    S * 2 743 730 176 plus the one-time modulation tables (cond MLP + 144 low-rank refinements for 40 timesteps)."""
+    D, F, Lz, L, R, E = 2048, 5888, 80, 24, 256, 512
+    per_row = S * (2 * L * (5 * D * D + 3 * D * F) + 2 * 2 * Lz * D)
+    rows = 20 * 3 + 20
+    mod = 2 * STEPS * (E * D + D * D + D * 3 * D) + 2 * STEPS * (2 * L * 3) * (2 * D * R)
+    return float(rows * per_row + mod)
+
+
+def build(device, rank: int, world: int):
+    import echo_tts_amd as E
+    from echo_tts_amd import parallel as P
+    from echo_tts_amd.weights import dac_param_shapes, dit_param_shapes, random_dac_state, random_dit_state
+    cfg, dcfg = E.EchoDiTConfig(), E.DACConfig()
+    # frozen weights: rank 0 draws them, everyone else receives them over RCCL (one broadcast, bucketed)
+    sd = random_dit_state(cfg, device, torch.bfloat16, seed=0) if rank == 0 else None
+    sd = P.broadcast_state(dit_param_shapes(cfg, with_blockwise=False), sd, device, torch.bfloat16)
+    model = E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device)
+    del sd
+    dsd = random_dac_state(dcfg, device, seed=0) if rank == 0 else None
+    dsd = P.broadcast_state(dac_param_shapes(dcfg), dsd, device, torch.float32)
+    dac = E.DAC(dcfg, dsd, device=device)
+    del dsd
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(1234)
+    q, _ = torch.linalg.qr(torch.randn(dcfg.latent_dim, cfg.latent_size, generator=g))
+    pca = E.PCAState(q.T.contiguous().to(device), (0.1 * torch.randn(dcfg.latent_dim, generator=g)).to(device), 1.0)
+    ids = torch.zeros((1, TT), dtype=torch.int32)
+    ids[0, 1:TVALID] = torch.randint(32, 127, (TVALID - 1,), generator=g, dtype=torch.int32)
+    tmask = torch.zeros((1, TT), dtype=torch.bool)
+    tmask[0, :TVALID] = True
+    spk = torch.randn((1, TS, cfg.latent_size), generator=g).to(device)
+    smask = torch.ones((1, TS), dtype=torch.bool)
+    return E, model, dac, pca, ids.to(device), tmask, spk, smask
+
+
+def cpu_baseline(threads: int):
+    """The CPU oracle (plain PyTorch restatement of the reference, bf16 DiT + fp32 DAC like the GPU run) on the host
+    cores, on a bounded sample of the same workload, extrapolated linearly in layers / steps / frames."""
+    from oracle import echo_ref as R
+    torch.set_num_threads(threads)
+    nl = 2
+    cfg = R.DiTConfig(num_layers=nl, text_num_layers=1, speaker_num_layers=1)
+    w = {k: v.bfloat16() for k, v in R.make_dit_weights(cfg, seed=0, with_blockwise=False).items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, S, 80), generator=g).bfloat16()
+    tm = torch.zeros((1, TVALID), dtype=torch.bool)
+    tm[:] = True
+    sm = torch.ones((1, TS // 4), dtype=torch.bool)
+    kvt = [(torch.randn((1, TVALID, 16, 128), generator=g).bfloat16(), torch.randn((1, TVALID, 16, 128), generator=g).bfloat16())
+           for _ in range(nl)]
+    kvs = [(torch.randn((1, TS // 4, 16, 128), generator=g).bfloat16(), torch.randn((1, TS // 4, 16, 128), generator=g).bfloat16())
+           for _ in range(nl)]
+    smf = torch.ones((1, TS), dtype=torch.bool)
+    with torch.inference_mode():
+        def fwd(rows):
+            xx = torch.cat([x] * rows, 0)
+            tt = torch.full((rows,), 0.7).bfloat16()
+            k3 = [(torch.cat([k] * rows, 0), torch.cat([v] * rows, 0)) for k, v in kvt]
+            s3 = [(torch.cat([k] * rows, 0), torch.cat([v] * rows, 0)) for k, v in kvs]
+            t0 = time.perf_counter()
+            R.dit_forward(w, cfg, xx, tt, torch.cat([tm] * rows, 0), torch.cat([smf] * rows, 0), k3, s3)
+            return time.perf_counter() - t0
+        fwd(1)
+        t3, t1 = fwd(3), fwd(1)
+        dcfg = R.DacConfig()
+        dw = R.make_dac_weights(dcfg, 0)
+        z = torch.randn((1, dcfg.latent_dim, 16), generator=g)
+        t0 = time.perf_counter()
+        R.dac_decode_zq(dw, dcfg, z)
+        tdac = time.perf_counter() - t0
+    est = (20 * t3 + 20 * t1) * (24 / nl) + tdac * (S / 16)
+    return {"value": AUDIO_S / est, "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/echo_ref.py, torch CPU eager bf16 DiT + fp32 DAC: one 3-row and one 1-row EchoDiT forward at S=640 with "
+                      f"{nl} of 24 layers ({t3:.2f}s, {t1:.2f}s) scaled x12 layers x20 steps each, DAC decode of 16 of 640 frames "
+                      f"({tdac:.2f}s) scaled x40; KV encoders excluded; estimated {est:.0f}s per utterance"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from echo_tts_amd import parallel as P
+    rank, world, local = P.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    E, model, dac, pca, ids, tmask, spk, smask = build(device, rank, world)
+
+    def utterance(seed: int):
+        lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=seed, **SAMPLER)
+        return E.ae_decode(dac, pca, lat)
+
+    for i in range(args.warmup):
+        utterance(1000 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wav = utterance(rank * 100000 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(wav).all()), "non-finite waveform"
+
+    roofline = None
+    phases = None
+    if rank == 0 and not args.no_roofline:
+        # live HIP-event timing of every gemm_nt launch of one sampler run (events on the launch stream)
+        model.set_profiling(True)
+        lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=7, **SAMPLER)
+        pr = model.get_profile()
+        model.set_profiling(False)
+        flops = dit_gemm_flops()
+        ach = flops / (pr.ms_gemm_sum * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_nt<bf16> (EchoDiT linears)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": pr.n_gemm, "avg_launch_us": round(1e3 * pr.ms_gemm_sum / max(pr.n_gemm, 1), 2),
+                    "flops_per_launch": flops / max(pr.n_gemm, 1)}
+        dac.set_profiling(True)
+        E.ae_decode(dac, pca, lat)
+        dp = dac.get_profile()
+        dac.set_profiling(False)
+        phases = {"sampler_ms": round(pr.ms_total, 2), "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
+                  "dac_decode_ms": round(dp.ms_total, 2), "dac_gemm_ms": round(dp.ms_gemm_sum, 2)}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(os.cpu_count() or 1)
+
+    if rank == 0:
+        total_audio = AUDIO_S * args.steps * world
+        out = {
+            "metric": "audio-sec/sec/GPU @ seq_len=640, 40 steps, CFG(text=3, spk=8); 1/2/4/8 GPU",
+            "value": round(total_audio / dt, 3), "unit": "audio-s/s (whole job; divide by n_gpus for per-GPU)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "per_gpu": round(total_audio / dt / world, 3),
+            "config": {"workload": "C2: 1 utterance/step/GPU, seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
+                                   "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
+                                   "EchoDiT bf16 + Fish S1-DAC decode fp32, random weights",
+                       "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
+            "roofline": roofline, "cpu_baseline": cpu, "phases": phases,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

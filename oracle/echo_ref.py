@@ -691,20 +691,28 @@ def make_dit_weights(cfg: DiTConfig, seed: int = 0, with_blockwise: bool = True)
 
 
 def make_dac_weights(cfg: DacConfig, seed: int = 0) -> Weights:
-    """Seeded random decode-path DAC weights with the reference's key names (weight-norm kept unfolded)."""
+    """Seeded random decode-path DAC weights with the reference's key names (weight-norm kept unfolded).
+
+    Gains are chosen so that the random network is well conditioned (waveform RMS ~1e-2, like the
+    reference's own init): unit-variance fan-in init, conv gain 0.5 through the
+    weight-norm g, small layer scales.  With gain 1 the tanh saturates and the net amplifies fp32
+    rounding noise to ~5e-5, which would make a 1e-4 waveform tolerance meaningless.
+    """
     g = torch.Generator().manual_seed(seed)
     w: Weights = {}
 
     def rnd(*shape: int, std: float = 0.02) -> Tensor:
         return torch.randn(shape, generator=g) * std
 
+    def lin(co: int, ci: int) -> Tensor:
+        return rnd(co, ci, std=1.0 / math.sqrt(ci))
+
     def wn_conv(p: str, co: int, ci: int, k: int, transpose: bool = False) -> None:
         shape = (ci, co, k) if transpose else (co, ci, k)
-        fan = ci * k
-        v = rnd(*shape, std=1.0 / math.sqrt(fan))
+        v = rnd(*shape, std=1.0 / math.sqrt(ci * k))
         w[f"{p}.conv.parametrizations.weight.original1"] = v
         gshape = (shape[0], 1, 1)
-        w[f"{p}.conv.parametrizations.weight.original0"] = v.flatten(1).norm(dim=1).view(gshape) * \
+        w[f"{p}.conv.parametrizations.weight.original0"] = 0.5 * v.flatten(1).norm(dim=1).view(gshape) * \
             (1.0 + 0.05 * torch.randn(gshape, generator=g))
         w[f"{p}.conv.bias"] = rnd(co)
 
@@ -712,15 +720,15 @@ def make_dac_weights(cfg: DacConfig, seed: int = 0) -> Weights:
     pm = "quantizer.post_module"
     for i in range(cfg.post_layers):
         lp = f"{pm}.layers.{i}"
-        w[f"{lp}.attention.wqkv.weight"] = rnd(3 * nh * hd, d)
-        w[f"{lp}.attention.wo.weight"] = rnd(d, nh * hd)
-        w[f"{lp}.feed_forward.w1.weight"] = rnd(cfg.post_ffn, d)
-        w[f"{lp}.feed_forward.w3.weight"] = rnd(cfg.post_ffn, d)
-        w[f"{lp}.feed_forward.w2.weight"] = rnd(d, cfg.post_ffn)
+        w[f"{lp}.attention.wqkv.weight"] = lin(3 * nh * hd, d)
+        w[f"{lp}.attention.wo.weight"] = lin(d, nh * hd)
+        w[f"{lp}.feed_forward.w1.weight"] = lin(cfg.post_ffn, d)
+        w[f"{lp}.feed_forward.w3.weight"] = lin(cfg.post_ffn, d)
+        w[f"{lp}.feed_forward.w2.weight"] = lin(d, cfg.post_ffn)
         w[f"{lp}.ffn_norm.weight"] = 1.0 + rnd(d, std=0.1)
         w[f"{lp}.attention_norm.weight"] = 1.0 + rnd(d, std=0.1)
-        w[f"{lp}.attention_layer_scale.gamma"] = 0.5 + rnd(d, std=0.1)
-        w[f"{lp}.ffn_layer_scale.gamma"] = 0.5 + rnd(d, std=0.1)
+        w[f"{lp}.attention_layer_scale.gamma"] = 0.2 + rnd(d, std=0.05)
+        w[f"{lp}.ffn_layer_scale.gamma"] = 0.2 + rnd(d, std=0.05)
     w[f"{pm}.norm.weight"] = 1.0 + rnd(d, std=0.1)
     for i in range(len(cfg.upsample_factors)):
         f = list(reversed(cfg.upsample_factors))[i]
@@ -731,11 +739,11 @@ def make_dac_weights(cfg: DacConfig, seed: int = 0) -> Weights:
         w[f"{up}.1.dwconv.conv.bias"] = rnd(d)
         w[f"{up}.1.norm.weight"] = 1.0 + rnd(d, std=0.1)
         w[f"{up}.1.norm.bias"] = rnd(d)
-        w[f"{up}.1.pwconv1.weight"] = rnd(4 * d, d)
+        w[f"{up}.1.pwconv1.weight"] = lin(4 * d, d)
         w[f"{up}.1.pwconv1.bias"] = rnd(4 * d)
-        w[f"{up}.1.pwconv2.weight"] = rnd(d, 4 * d)
+        w[f"{up}.1.pwconv2.weight"] = lin(d, 4 * d)
         w[f"{up}.1.pwconv2.bias"] = rnd(d)
-        w[f"{up}.1.gamma"] = 0.5 + rnd(d, std=0.1)
+        w[f"{up}.1.gamma"] = 0.3 + rnd(d, std=0.05)
     dm = "decoder.model"
     ch = cfg.decoder_dim
     wn_conv(f"{dm}.0", ch, d, 7)
