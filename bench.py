@@ -118,6 +118,18 @@ def cpu_baseline(threads: int):
                       f"({tdac:.2f}s) scaled x40; KV encoders excluded; estimated {est:.0f}s per utterance"}
 
 
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask, cgroup quota, capped at the box's 16-core share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +193,7 @@ def main() -> None:
                   "dac_decode_ms": round(dp.ms_total, 2), "dac_gemm_ms": round(dp.ms_gemm_sum, 2)}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(os.cpu_count() or 1)
+        cpu = cpu_baseline(host_threads())
 
     if rank == 0:
         total_audio = AUDIO_S * args.steps * world

@@ -141,85 +141,107 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane (fr, fh) holds, for output row m = .. + fr, columns n0 + 8g + 4fh + 0..3
+  // ---- epilogue.  The accumulators go through LDS (the staging buffers are free now): each lane
+  // writes its 4-column runs as 16-byte chunks into a [128][32 chunks] fp32 image (chunk ^= row & 31
+  // against bank conflicts); the tile is then re-read row-wise so that 32 consecutive lanes cover one
+  // output row: global stores are whole 256/512-byte row segments and the fused tail below is
+  // emitted once (a runtime loop) instead of 16 times per lane.
+  __syncthreads();
+  {
+    float* sc = (float*)smem;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = wm * 64 + tm * 32 + fr;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int chunk = wn * 16 + tn * 8 + 2 * g + fh;
+          f32x4 v;
+          v[0] = acc[tn][tm][4 * g]; v[1] = acc[tn][tm][4 * g + 1]; v[2] = acc[tn][tm][4 * g + 2]; v[3] = acc[tn][tm][4 * g + 3];
+          *(f32x4*)(sc + (m * 32 + (chunk ^ (m & 31))) * 4) = v;
+        }
+    }
+  }
+  __syncthreads();
   typedef Vec4<T> V;
+  const float* sc = (const float*)smem;
   T* C = (T*)p.C + c_z;
   T* C2 = (T*)p.C2 + c_z;
   const int vm = p.vec_mod;
+  if constexpr (SWIGLU) {
+    // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      const int idx = j * 256 + tid;
+      const int ml = idx >> 4, pc = idx & 15;
+      const int b = pc >> 2, q = pc & 3;
+      const int m = tile_m * BM + ml;
+      const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
+      const f32x4 a4 = *(const f32x4*)(sc + (ml * 32 + ((b * 8 + q) ^ (ml & 31))) * 4);
+      const f32x4 b4 = *(const f32x4*)(sc + (ml * 32 + ((b * 8 + 4 + q) ^ (ml & 31))) * 4);
+      float o[4];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = tile_m * BM + wm * 64 + tm * 32 + fr;
-    if (m >= p.M) continue;
+      for (int i = 0; i < 4; ++i) {
+        const float a = Num<T>::rnd(a4[i]);
+        const float bb = Num<T>::rnd(b4[i]);
+        o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
+      }
+      if (m < p.M && j0 < (p.N >> 1)) *(typename V::raw*)(C + (long)m * p.ldc + j0) = V::pack(o);
+    }
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+      const int idx = j * 256 + tid;
+      const int ml = idx >> 5, chunk = idx & 31;
+      const int m = tile_m * BM + ml;
+      const int n0 = tile_n * BN + chunk * 4;
+      if (m >= p.M || n0 >= p.N) continue;
+      const f32x4 a4 = *(const f32x4*)(sc + (ml * 32 + (chunk ^ (ml & 31))) * 4);
+      float y[4] = {a4[0], a4[1], a4[2], a4[3]};
+      if (p.acc_scale != 1.0f) {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int nb = tile_n * BN + wn * 64 + tn * 32;
-      if constexpr (SWIGLU) {
+        for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
+      }
+      const int nv = vm ? n0 % vm : n0;
+      if (p.bias) {
+        const long bo = zo * p.bias_bo + zi * p.bias_bi;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int j0 = (nb >> 1) + 8 * g + 4 * fh;
-          if (j0 >= (p.N >> 1)) continue;
-          float o[4];
+        for (int i = 0; i < 4; ++i) y[i] += vec_at<T>(p.bias, bo + nv + i);
+      }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float a = Num<T>::rnd(acc[tn][tm][4 * g + i]);
-            const float b = Num<T>::rnd(acc[tn][tm][4 * (g + 2) + i]);
-            o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * b);
-          }
-          *(typename V::raw*)(C + (long)m * p.ldc + j0) = V::pack(o);
+      for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
+      if (p.div != 0.0f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(gelu_erf_f(y[i]));
+      }
+      if (p.colscale) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * vec_at<T>(p.colscale, nv + i));
+      }
+      if (p.res) {
+        float r[4];
+        V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
+      }
+      if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
+      if (p.snake_alpha) {
+        float sn4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float al = vec_at<T>(p.snake_alpha, nv + i);
+          const float sn = sinf(al * y[i]);
+          sn4[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
         }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n0 = nb + 8 * g + 4 * fh;
-          if (n0 >= p.N) continue;
-          float y[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = acc[tn][tm][4 * g + i];
-          if (p.acc_scale != 1.0f) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
-          }
-          const int nv = vm ? n0 % vm : n0;
-          if (p.bias) {
-            const long bo = zo * p.bias_bo + zi * p.bias_bi;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] += vec_at<T>(p.bias, bo + nv + i);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
-          if (p.div != 0.0f) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
-          }
-          if (p.act == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
-          } else if (p.act == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(gelu_erf_f(y[i]));
-          }
-          if (p.colscale) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * vec_at<T>(p.colscale, nv + i));
-          }
-          if (p.res) {
-            float r[4];
-            V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
-          }
-          if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
-          if (p.snake_alpha) {
-            float s[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float al = vec_at<T>(p.snake_alpha, nv + i);
-              const float sn = sinf(al * y[i]);
-              s[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
-            }
-            *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(s);
-          }
-        }
+        *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
       }
     }
   }
