@@ -114,3 +114,18 @@ def test_conv_weight_reshapes_are_consistent():
     rows = torch.stack([torch.cat([xp[q], xp[q + 1]]) for q in range(20)])
     out = (rows @ _convT_as_gemm(wt, 4).T).reshape(80, 4)
     assert torch.allclose(out, ref)
+
+
+def test_handler_helpers_kat(golden):
+    from echo_tts_amd import handler as H
+    host = golden["__meta__"]["host"]
+    for case in host["chunk_text_for_audio"]:
+        assert H.chunk_text_for_audio(case["text"], case["max_chars"], case["dur"]) == case["chunks"]
+    a, b, c = golden["post.a"], golden["post.b"], golden["post.c"]
+    assert torch.equal(H.crossfade_chunks([a, b, c], 4410), golden["post.crossfade"])
+    assert torch.equal(H.normalize_chunk_boundaries([a, b, c], min_silence_samples=2000), golden["post.normalize"])
+    assert H.crossfade_chunks([]).numel() == 0 and torch.equal(H.crossfade_chunks([a]), a)
+    fn = H._build_sample_fn({"num_steps": 12})
+    assert fn.keywords["num_steps"] == 12 and fn.keywords["cfg_scale_speaker"] == 8.0 and fn.keywords["sequence_length"] == 640
+    out = H.synthesize({"text": "   "}, None, None, None)
+    assert out["error_type"] == "ValueError"
