@@ -63,7 +63,8 @@ class EchoGemmDesc(C.Structure):
                 ("colscale", vp),
                 ("res", vp), ("ldres", c_i64), ("res_bo", c_i64), ("res_bi", c_i64),
                 ("snake_alpha", vp),
-                ("store_main", C.c_int), ("swiglu", C.c_int)]
+                ("store_main", C.c_int), ("swiglu", C.c_int),
+                ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64)]
 
 
 class EchoAttnSeg(C.Structure):

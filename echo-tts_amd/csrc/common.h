@@ -93,7 +93,12 @@ struct GemmArgs {
   const void* snake_alpha;      // C2[m][n] = rnd(snake(y, alpha[n]))
   int store_main;               // write y to C
   int swiglu;                   // W rows interleaved [16 x w1 | 16 x w3]; C has N/2 columns
+  int cfg;                      // tile configuration (gemm.hip TileCfg table), 0 = 128x128x2 stages
+  int ksplit;                   // > 1: split K over blockIdx.z, fp32 partial slabs in ws, reduce kernel applies the tail
+  void* ws; long ws_bytes;
 };
+int gemm_tile_m(int cfg);
+int gemm_num_cfgs();
 void gemm_args_init(GemmArgs* g);
 template <typename T> hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st);
 

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -136,6 +137,7 @@ struct Engine : EngineBase {
   ~Engine() override {
     for (void* p : owned) (void)hipFree(p);
     for (DevBuf* b : all_bufs()) b->release();
+    b_gemm_ws.release(); b_tune_c.release();
   }
 
   // ------------------------------------------------------------------ weights
@@ -209,7 +211,71 @@ struct Engine : EngineBase {
     g.Npad = (int)rup(N, 128);
     return g;
   }
-  int run(const GemmArgs& g, hipStream_t st) {
+  // ------------------------------------------------------------------ GEMM plans (tile config + split-K per shape)
+  struct Plan { int cfg = 0, ksplit = 1; };
+  std::map<std::vector<long>, Plan> plans;
+  DevBuf b_gemm_ws, b_tune_c;
+  bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : true;
+
+  template <typename U>
+  int plan_gemm(GemmArgs& g, hipStream_t st) {
+    const int KEu = 128 / (int)sizeof(U);
+    const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U)};
+    auto it = plans.find(key);
+    if (it == plans.end()) {
+      Plan best;
+      const int nk = g.K / KEu * g.taps;
+      const long t128 = (long)((g.M + 127) / 128) * (g.Npad / 128);
+      if (tune_enabled && (long)g.M * g.N * g.K * g.taps >= (1L << 28)) {
+        // time every candidate on the real operands with a scratch output (the tail is irrelevant for the ranking)
+        GemmArgs t = g;
+        const long out_el = ((long)g.M + 256) * (g.ldc > g.Npad ? g.ldc : g.Npad);
+        CK(b_tune_c.reserve((size_t)out_el * sizeof(U) * (g.nbatch > 1 ? 1 : 1)));
+        t.C = b_tune_c.p; t.C2 = nullptr; t.res = nullptr; t.snake_alpha = nullptr; t.store_main = 1; t.colscale = nullptr; t.bias = nullptr;
+        if (g.nbatch > 1) { t.nbatch = 1; t.nbi = 1; }
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best_ms = 1e30f;
+        for (int cfg = 0; cfg < gemm_num_cfgs(); ++cfg) {
+          for (int ksp = 1; ksp <= 8; ksp *= 2) {
+            if (ksp > 1 && (g.nbatch > 1 || nk / ksp < 4 || t128 * ksp > 1024)) continue;
+            t.cfg = cfg; t.ksplit = ksp;
+            if (ksp > 1) {
+              const long need = (long)ksp * (((long)g.M + 255) / 256 * 256) * g.Npad * 4;
+              CK(b_gemm_ws.reserve((size_t)need));
+              t.ws = b_gemm_ws.p; t.ws_bytes = (long)b_gemm_ws.cap;
+            }
+            hipError_t le = launch_gemm_nt<U>(t, st);   // warm
+            if (le != hipSuccess) continue;
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < 3; ++r) CK(launch_gemm_nt<U>(t, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best_ms) { best_ms = ms; best.cfg = cfg; best.ksplit = ksp; }
+          }
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (getenv("ECHO_GEMM_VERBOSE"))
+          fprintf(stderr, "[echo] gemm plan M=%d N=%d K=%d taps=%d swiglu=%d T=%d: cfg %d ksplit %d (%.1f us)\n", g.M, g.N, g.K, g.taps,
+                  g.swiglu, (int)sizeof(U), best.cfg, best.ksplit, best_ms * 1e3f / 3);
+      }
+      it = plans.emplace(key, best).first;
+    }
+    g.cfg = it->second.cfg;
+    g.ksplit = it->second.ksplit;
+    if (g.ksplit > 1) {
+      const long need = (long)g.ksplit * (((long)g.M + 255) / 256 * 256) * g.Npad * 4;
+      CK(b_gemm_ws.reserve((size_t)need));
+      g.ws = b_gemm_ws.p; g.ws_bytes = (long)b_gemm_ws.cap;
+    }
+    return ECHO_OK;
+  }
+
+  int run(const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
+    CKI(plan_gemm<T>(g, st));
     if (profiling) {
       if (gemm_events_used == gemm_events.size()) {
         hipEvent_t a, b;
@@ -981,7 +1047,9 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
 
-  int frun(const GemmArgs& g, hipStream_t st) {
+  int frun(const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
+    CKI(plan_gemm<float>(g, st));
     if (profiling) {
       if (gemm_events_used == gemm_events.size()) {
         hipEvent_t a, b;
@@ -1298,6 +1366,7 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.bias = d->bias; g.bias_bo = d->bias_bo; g.bias_bi = d->bias_bi; g.vec_mod = d->vec_mod; g.div = d->div; g.act = d->act;
   g.colscale = d->colscale; g.res = d->res; g.ldres = d->ldres; g.res_bo = d->res_bo; g.res_bi = d->res_bi;
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
+  g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
 }
 int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,

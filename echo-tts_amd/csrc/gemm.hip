@@ -3,7 +3,9 @@
 // nn.Linear in model.py / autoencoder.py) and, through the `taps` loop, every causal Conv1d /
 // ConvTranspose1d of the DAC decoder in channels-last layout (autoencoder.py:264-331).
 //
-// Tile: 128 (m) x 128 (n) per 256-thread workgroup, K-step = 128 bytes per row (64 bf16 / 32 fp32).
+// Tile configurations (TileCfg): 128x128 / 256x128 / 128x256 / 256x256 output tiles, 4 or 8 waves, 2-4 LDS
+// stages with a counted-vmcnt DMA pipeline; K-step = 128 bytes per row (64 bf16 / 32 fp32); optional split-K
+// with fp32 partial slabs and a deterministic reduce + tail kernel.
 // Both operands are K-contiguous, so A and W tiles are staged the same way: direct global->LDS
 // DMA (global_load_lds_dwordx4), lane-linear LDS image, XOR swizzle applied on the SOURCE address
 // (chunk ^= (row>>1)&7) and again on the ds_read_b128 address, which makes every fragment read
@@ -20,10 +22,7 @@ void gemm_args_init(GemmArgs* g) {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, KBYTES = 128;
-constexpr int TILE_BYTES = BM * KBYTES;           // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + W
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // double buffered: 64 KiB
+constexpr int KBYTES = 128;   // K step: 128 bytes per row (64 bf16 / 32 fp32)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -32,15 +31,97 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <typename T>
 __device__ __forceinline__ float vec_at(const void* p, long i) { return Num<T>::ld(((const T*)p)[i]); }
 
-template <typename T, bool SWIGLU>
-__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmArgs p) {
+// Tile configuration: BM x BN output tile, NWM x NWN waves (each wave (BM/NWM) x (BN/NWN)), STAGES LDS buffers.
+template <int BM_, int BN_, int NWM_, int NWN_, int STAGES_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, NWM = NWM_, NWN = NWN_, STAGES = STAGES_;
+  static constexpr int NW = NWM * NWN, NT = NW * 64;
+  static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+  static constexpr int STAGE_BYTES = (BM + BN) * KBYTES;
+  static constexpr int SMEM = STAGES * STAGE_BYTES;
+  static constexpr int PIECES = (BM + BN) / 8;          // 1 KiB DMA pieces (8 rows x 128 B) per stage
+  static constexpr int PPW = PIECES / NW;               // pieces per wave
+  static constexpr int WAVES_PER_SIMD = NW / 4 * (SMEM <= 80 * 1024 ? 2 : 1);
+  static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(32 * BN * 4 <= SMEM, "epilogue slab must fit");
+};
+
+// ---- fused tail (one rounding to T wherever eager PyTorch materialises a tensor)
+template <typename T>
+__device__ __forceinline__ void gemm_tail(const GemmArgs& p, int m, int n0, float (&y)[4], int zo, int zi, T* C, T* C2) {
+  typedef Vec4<T> V;
+  if (p.acc_scale != 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
+  }
+  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
+  if (p.bias) {
+    const long bo = zo * p.bias_bo + zi * p.bias_bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] += vec_at<T>(p.bias, bo + nv + i);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
+  if (p.div != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(gelu_erf_f(y[i]));
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * vec_at<T>(p.colscale, nv + i));
+  }
+  if (p.res) {
+    float r[4];
+    V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
+  }
+  if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
+  if (p.snake_alpha) {
+    float sn4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float al = vec_at<T>(p.snake_alpha, nv + i);
+      const float sn = sinf(al * y[i]);
+      sn4[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
+    }
+    *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, const f32x4& a4, const f32x4& b4, T* C) {
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = Num<T>::rnd(a4[i]);
+    const float bb = Num<T>::rnd(b4[i]);
+    o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
+  }
+  *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + j0) = Vec4<T>::pack(o);
+}
+
+template <typename T, bool SWIGLU, typename CF>
+__global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = KBYTES / (int)sizeof(T);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.Npad / BN;
+  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, PPW = CF::PPW, STAGES = CF::STAGES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Npad + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {  // bijective XCD remap: workgroups that share an XCD (bid % 8) get a contiguous run of tiles
@@ -51,227 +132,280 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmArgs p) {
   const int z = blockIdx.y, zo = z / p.nbi, zi = z - zo * p.nbi;
   const long a_z = zo * p.a_bo + zi * p.a_bi, w_z = zo * p.w_bo + zi * p.w_bi, c_z = zo * p.c_bo + zi * p.c_bi;
 
-  // ---- staging addresses: wave w issues DMA pieces 4w..4w+3, each 8 rows x 128 B
-  const char* asrc[4];
-  const char* wsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wid * 4 + i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-    int gm = tile_m * BM + r;
-    gm = gm < p.M ? gm : p.M - 1;
-    asrc[i] = (const char*)p.A + ((long)(gm + p.tap_base) * p.lda + a_z) * (long)sizeof(T) + chunk * 16;
-    const int gn = tile_n * BN + r;
-    wsrc[i] = (const char*)p.W + ((long)gn * p.ldw + w_z) * (long)sizeof(T) + chunk * 16;
-  }
+  // ---- K range of this workgroup (split-K over blockIdx.z)
   const int kb_per_tap = p.K / KE;
-  const int nk = kb_per_tap * p.taps;
-  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * (long)sizeof(T);  // extra step at a tap boundary
+  const int nk_total = kb_per_tap * p.taps;
+  const int ks = p.ksplit > 1 ? p.ksplit : 1;
+  const int split = blockIdx.z;
+  const int it0 = (int)((long)nk_total * split / ks), it1 = (int)((long)nk_total * (split + 1) / ks);
+  const int nk = it1 - it0;
 
-  auto stage = [&](int buf, long a_off, long w_off) {
-    char* base = smem + buf * STAGE_BYTES + wid * 4096;
+  // ---- DMA sources: wave w owns pieces w*PPW .. w*PPW+PPW-1 of the combined [A rows | W rows] stage image
+  const char* src[PPW];
+  bool is_a[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(asrc[i] + a_off, base + i * 1024);
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wid * PPW + i;
+    const int r = piece * 8 + (lane >> 3);            // row inside the stage image
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);    // source-side swizzle (BM is a multiple of 16)
+    is_a[i] = piece * 8 < BM;
+    if (is_a[i]) {
+      int gm = tile_m * BM + r;
+      gm = gm < p.M ? gm : p.M - 1;
+      src[i] = (const char*)p.A + ((long)(gm + p.tap_base) * p.lda + a_z) * (long)sizeof(T) + chunk * 16;
+    } else {
+      int gn = tile_n * BN + (r - BM);
+      gn = gn < p.Npad ? gn : p.Npad - 1;
+      src[i] = (const char*)p.W + ((long)gn * p.ldw + w_z) * (long)sizeof(T) + chunk * 16;
+    }
+  }
+  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * (long)sizeof(T);  // extra A step at a tap boundary
+  int kb = it0 % kb_per_tap;
+  long a_off = (long)(it0 / kb_per_tap) * p.tap_shift * p.lda * (long)sizeof(T) + (long)kb * KBYTES;
+  long w_off = (long)it0 * KBYTES;
+
+  auto stage = [&](int slot) {
+    char* base = smem + slot * CF::STAGE_BYTES + wid * (PPW * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(wsrc[i] + w_off, base + TILE_BYTES + i * 1024);
+    for (int i = 0; i < PPW; ++i) glds16(src[i] + (is_a[i] ? a_off : w_off), base + i * 1024);
+    a_off += KBYTES; w_off += KBYTES;
+    if (++kb == kb_per_tap) { kb = 0; a_off += a_tap_bytes; }
   };
 
-  // ---- fragment read addresses (bytes inside a tile)
-  const int wn = wid & 1, wm = wid >> 1;
+  // ---- fragment read addresses
+  const int wm = wid / CF::NWN, wn = wid % CF::NWN;
   const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (lane >> 1) & 7;  // == ((row >> 1) & 7) because the row bases are multiples of 16
-  const int a_row0 = (wm * 64 + fr) * KBYTES, w_row0 = (wn * 64 + fr) * KBYTES;
+  const int sw = (lane >> 1) & 7;   // == ((row >> 1) & 7): all row bases are multiples of 16
+  const int a_row0 = (wm * CF::WM + fr) * KBYTES;
+  const int w_row0 = (BM + wn * CF::WN + fr) * KBYTES;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TN][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  long a_off = 0, w_off = 0;
-  int kb = 0;
-  stage(0, a_off, w_off);
+  // ---- pipeline: STAGES-1 tiles in flight
+  int issued = 0;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (issued < nk) { stage(s); ++issued; }
+
   for (int it = 0; it < nk; ++it) {
-    __syncthreads();  // (vmcnt(0) + barrier): stage `it` has landed, everyone is done with the other buffer
-    if (it + 1 < nk) {
-      a_off += KBYTES; w_off += KBYTES;
-      if (++kb == kb_per_tap) { kb = 0; a_off += a_tap_bytes; }
-      stage((it + 1) & 1, a_off, w_off);
-    }
-    const char* sa = smem + (it & 1) * STAGE_BYTES;
-    const char* swt = sa + TILE_BYTES;
+    // tile `it` must have landed: allow (tiles still in flight - 1) * PPW younger DMA pieces to stay outstanding
+    const int younger = issued - it - 1;
+    if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * PPW>();
+    else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile `it` are in LDS; everyone finished reading tile it-1
+    if (issued < nk) { stage((it + STAGES - 1) % STAGES); ++issued; }
+
+    const char* sa = smem + (it % STAGES) * CF::STAGE_BYTES;
     if constexpr (Num<T>::is_bf16) {
+      bf16x8 wf[2][TN], af[2][TM];
+      auto load = [&](int kk, int b) {
+        const int c = ((2 * kk + fh) ^ sw) << 4;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) wf[b][t] = *(const bf16x8*)(sa + w_row0 + t * 32 * KBYTES + c);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[b][t] = *(const bf16x8*)(sa + a_row0 + t * 32 * KBYTES + c);
+      };
+      load(0, 0);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int c = ((2 * kk + fh) ^ sw) << 4;
-        bf16x8 wf[2], af[2];
+        if (kk < 3) load(kk + 1, (kk + 1) & 1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          wf[t] = *(const bf16x8*)(swt + w_row0 + t * 32 * KBYTES + c);
-          af[t] = *(const bf16x8*)(sa + a_row0 + t * 32 * KBYTES + c);
-        }
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+          for (int tm = 0; tm < TM; ++tm)
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tn], af[kk & 1][tm], acc[tn][tm], 0, 0, 0);
       }
     } else {
+      f32x4 wf[2][TN], af[2][TM];
+      auto load = [&](int cc, int b) {
+        const int c = (cc ^ sw) << 4;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) wf[b][t] = *(const f32x4*)(sa + w_row0 + t * 32 * KBYTES + c);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[b][t] = *(const f32x4*)(sa + a_row0 + t * 32 * KBYTES + c);
+      };
+      load(0, 0);
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
-        const int c = (cc ^ sw) << 4;
-        f32x4 wf[2], af[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          wf[t] = *(const f32x4*)(swt + w_row0 + t * 32 * KBYTES + c);
-          af[t] = *(const f32x4*)(sa + a_row0 + t * 32 * KBYTES + c);
-        }
+        if (cc < 7) load(cc + 1, (cc + 1) & 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
+          for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-              acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fh ? wf[tn][2 * s + 1] : wf[tn][2 * s],
-                                                                 fh ? af[tm][2 * s + 1] : af[tm][2 * s],
+            for (int tm = 0; tm < TM; ++tm)
+              acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fh ? wf[cc & 1][tn][2 * s + 1] : wf[cc & 1][tn][2 * s],
+                                                                 fh ? af[cc & 1][tm][2 * s + 1] : af[cc & 1][tm][2 * s],
                                                                  acc[tn][tm], 0, 0, 0);
       }
     }
   }
 
-  // ---- epilogue.  The accumulators go through LDS (the staging buffers are free now): each lane
-  // writes its 4-column runs as 16-byte chunks into a [128][32 chunks] fp32 image (chunk ^= row & 31
-  // against bank conflicts); the tile is then re-read row-wise so that 32 consecutive lanes cover one
-  // output row: global stores are whole 256/512-byte row segments and the fused tail below is
-  // emitted once (a runtime loop) instead of 16 times per lane.
-  __syncthreads();
-  {
-    float* sc = (float*)smem;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int m = wm * 64 + tm * 32 + fr;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int chunk = wn * 16 + tn * 8 + 2 * g + fh;
-          f32x4 v;
-          v[0] = acc[tn][tm][4 * g]; v[1] = acc[tn][tm][4 * g + 1]; v[2] = acc[tn][tm][4 * g + 2]; v[3] = acc[tn][tm][4 * g + 3];
-          *(f32x4*)(sc + (m * 32 + (chunk ^ (m & 31))) * 4) = v;
-        }
-    }
-  }
-  __syncthreads();
-  typedef Vec4<T> V;
-  const float* sc = (const float*)smem;
+  // ---- epilogue, 32 output rows per pass through LDS (the staging buffers are free after the last barrier):
+  // the owning waves write their accumulators as 16-byte chunks into a [32][BN/4] fp32 slab (chunk ^= row, conflict
+  // spreading), then all threads re-read it row-wise so that consecutive lanes cover consecutive columns of one row:
+  // global stores are whole row segments and the fused tail is emitted once.
   T* C = (T*)p.C + c_z;
   T* C2 = (T*)p.C2 + c_z;
-  const int vm = p.vec_mod;
-  if constexpr (SWIGLU) {
-    // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
+  float* slab = (float*)smem;
+  constexpr int CPR = BN / 4;               // chunks per slab row
+  constexpr int NPASS = BM / 32;
 #pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-      const int idx = j * 256 + tid;
-      const int ml = idx >> 4, pc = idx & 15;
-      const int b = pc >> 2, q = pc & 3;
-      const int m = tile_m * BM + ml;
-      const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
-      const f32x4 a4 = *(const f32x4*)(sc + (ml * 32 + ((b * 8 + q) ^ (ml & 31))) * 4);
-      const f32x4 b4 = *(const f32x4*)(sc + (ml * 32 + ((b * 8 + 4 + q) ^ (ml & 31))) * 4);
-      float o[4];
+  for (int pass = 0; pass < NPASS; ++pass) {
+    __builtin_amdgcn_s_waitcnt(0);          // (vmcnt/lgkmcnt drained; expcnt too)
+    __syncthreads();
+    if (wm == pass / TM) {
+      const int tm_sel = pass % TM;
+      auto put = [&](const f32x16& a, int tn) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a = Num<T>::rnd(a4[i]);
-        const float bb = Num<T>::rnd(b4[i]);
-        o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
-      }
-      if (m < p.M && j0 < (p.N >> 1)) *(typename V::raw*)(C + (long)m * p.ldc + j0) = V::pack(o);
-    }
-  } else {
-#pragma unroll 1
-    for (int j = 0; j < 16; ++j) {
-      const int idx = j * 256 + tid;
-      const int ml = idx >> 5, chunk = idx & 31;
-      const int m = tile_m * BM + ml;
-      const int n0 = tile_n * BN + chunk * 4;
-      if (m >= p.M || n0 >= p.N) continue;
-      const f32x4 a4 = *(const f32x4*)(sc + (ml * 32 + (chunk ^ (ml & 31))) * 4);
-      float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-      if (p.acc_scale != 1.0f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
-      }
-      const int nv = vm ? n0 % vm : n0;
-      if (p.bias) {
-        const long bo = zo * p.bias_bo + zi * p.bias_bi;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] += vec_at<T>(p.bias, bo + nv + i);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
-      if (p.div != 0.0f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(gelu_erf_f(y[i]));
-      }
-      if (p.colscale) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * vec_at<T>(p.colscale, nv + i));
-      }
-      if (p.res) {
-        float r[4];
-        V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
-      }
-      if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
-      if (p.snake_alpha) {
-        float sn4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float al = vec_at<T>(p.snake_alpha, nv + i);
-          const float sn = sinf(al * y[i]);
-          sn4[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
+        for (int g = 0; g < 4; ++g) {
+          const int chunk = wn * (CF::WN / 4) + tn * 8 + 2 * g + fh;
+          f32x4 v;
+          v[0] = a[4 * g]; v[1] = a[4 * g + 1]; v[2] = a[4 * g + 2]; v[3] = a[4 * g + 3];
+          *(f32x4*)(slab + (fr * CPR + (chunk ^ fr)) * 4) = v;
         }
-        *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
+      };
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        // static register indices only (a runtime-indexed accumulator array would live in scratch)
+        if (tm_sel == 0) put(acc[tn][0], tn);
+        if constexpr (TM > 1) { if (tm_sel == 1) put(acc[tn][1], tn); }
+        if constexpr (TM > 2) { if (tm_sel == 2) put(acc[tn][2], tn); }
+        if constexpr (TM > 3) { if (tm_sel == 3) put(acc[tn][3], tn); }
+      }
+    }
+    __syncthreads();
+    const int mrow0 = tile_m * BM + pass * 32;
+    if (p.ksplit > 1) {
+      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
+      float* ws = (float*)p.ws + ((long)split * tiles_m * BM + mrow0) * (long)p.Npad + (long)tile_n * BN;
+#pragma unroll 1
+      for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
+        const int ml = idx / CPR, chunk = idx % CPR;
+        if (tile_n * BN + chunk * 4 < p.Npad)
+          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+      }
+    } else if constexpr (SWIGLU) {
+      // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
+#pragma unroll 1
+      for (int idx = tid; idx < 32 * (CPR / 2); idx += CF::NT) {
+        const int ml = idx / (CPR / 2), pc = idx % (CPR / 2);
+        const int b = pc >> 2, q = pc & 3;
+        const int m = mrow0 + ml;
+        const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
+        if (m >= p.M || j0 >= (p.N >> 1)) continue;
+        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + q) ^ ml)) * 4);
+        const f32x4 b4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + 4 + q) ^ ml)) * 4);
+        swiglu_tail<T>(p, m, j0, a4, b4, C);
+      }
+    } else {
+#pragma unroll 1
+      for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
+        const int ml = idx / CPR, chunk = idx % CPR;
+        const int m = mrow0 + ml;
+        const int n0 = tile_n * BN + chunk * 4;
+        if (m >= p.M || n0 >= p.N) continue;
+        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+        float y[4] = {a4[0], a4[1], a4[2], a4[3]};
+        gemm_tail<T>(p, m, n0, y, zo, zi, C, C2);
       }
     }
   }
 }
 
-template <typename T, bool SW>
-hipError_t launch_impl(const GemmArgs& g, hipStream_t st) {
+// sums the split-K partial slabs in split order (deterministic) and applies the fused tail
+template <typename T, bool SWIGLU>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs p, int Mpad) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const float* ws = (const float*)p.ws;
+  const long slab = (long)Mpad * p.Npad;
+  if constexpr (SWIGLU) {
+    const int cpr = p.Npad / 8;                      // output chunks per row
+    const int m = (int)(idx / cpr), pc = (int)(idx % cpr);
+    const int blk = pc >> 2, q = pc & 3;             // 32-row packed block, 4-column group
+    const int j0 = blk * 16 + q * 4;
+    if (m >= p.M || j0 >= (p.N >> 1)) return;
+    f32x4 a4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0};
+    for (int s = 0; s < p.ksplit; ++s) {
+      const float* r = ws + s * slab + (long)m * p.Npad + blk * 32 + q * 4;
+      const f32x4 x = *(const f32x4*)r, y = *(const f32x4*)(r + 16);
+      a4 += x; b4 += y;
+    }
+    swiglu_tail<T>(p, m, j0, a4, b4, (T*)p.C);
+  } else {
+    const int cpr = p.Npad / 4;
+    const int m = (int)(idx / cpr), n0 = (int)(idx % cpr) * 4;
+    if (m >= p.M || n0 >= p.N) return;
+    f32x4 a4 = {0, 0, 0, 0};
+    for (int s = 0; s < p.ksplit; ++s) a4 += *(const f32x4*)(ws + s * slab + (long)m * p.Npad + n0);
+    float y[4] = {a4[0], a4[1], a4[2], a4[3]};
+    gemm_tail<T>(p, m, n0, y, 0, 0, (T*)p.C, (T*)p.C2);
+  }
+}
+
+template <typename T, bool SW, typename CF>
+hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<T, SW>;
+  auto kern = gemm_nt_kernel<T, SW, CF>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.Npad / BN;
-  dim3 grid(tiles_m * tiles_n, g.nbatch, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), SMEM_BYTES, st, g);
+  const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = (g.Npad + CF::BN - 1) / CF::BN;
+  const int ks = g.ksplit > 1 ? g.ksplit : 1;
+  dim3 grid(tiles_m * tiles_n, g.nbatch, ks);
+  hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::SMEM, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || ks == 1) return e;
+  const int Mpad = tiles_m * CF::BM;
+  const long items = (long)g.M * (SW ? g.Npad / 8 : g.Npad / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T, SW>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g, Mpad);
   return hipGetLastError();
+}
+
+typedef TileCfg<128, 128, 2, 2, 2> Cfg0;   // 4 waves, 64 KiB: two workgroups per CU
+typedef TileCfg<128, 128, 2, 2, 4> Cfg1;   // 4 waves, 128 KiB, 3 tiles in flight: latency-bound small grids
+typedef TileCfg<256, 256, 2, 4, 2> Cfg2;   // 8 waves (128x64 each), 128 KiB: lowest L2 traffic per FLOP
+typedef TileCfg<256, 128, 4, 2, 3> Cfg3;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
+typedef TileCfg<128, 256, 2, 4, 3> Cfg4;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
+
+template <typename T, bool SW>
+hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
+  switch (g.cfg) {
+    case 1: return launch_cfg<T, SW, Cfg1>(g, st);
+    case 2: return launch_cfg<T, SW, Cfg2>(g, st);
+    case 3: return launch_cfg<T, SW, Cfg3>(g, st);
+    case 4: return launch_cfg<T, SW, Cfg4>(g, st);
+    default: return launch_cfg<T, SW, Cfg0>(g, st);
+  }
 }
 
 }  // namespace
 
+int gemm_tile_m(int cfg) { return cfg == 2 || cfg == 3 ? 256 : 128; }
+int gemm_num_cfgs() { return 5; }
+
 template <typename T>
 hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   constexpr int KE = KBYTES / (int)sizeof(T);
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % BN != 0 || g.Npad < g.N || (g.N & 3) ||
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3))
+      (g.ldc & 3) || g.cfg < 0 || g.cfg >= gemm_num_cfgs())
     return hipErrorInvalidValue;
-  return g.swiglu ? launch_impl<T, true>(g, st) : launch_impl<T, false>(g, st);
+  if (g.ksplit > 1) {
+    if (g.nbatch != 1 || !g.ws || g.ksplit > (g.K / KE) * g.taps) return hipErrorInvalidValue;
+    const long need = (long)g.ksplit * ((g.M + gemm_tile_m(g.cfg) - 1) / gemm_tile_m(g.cfg)) * gemm_tile_m(g.cfg) * g.Npad * 4;
+    if (g.ws_bytes < need) return hipErrorInvalidValue;
+  }
+  return g.swiglu ? launch_sw<T, true>(g, st) : launch_sw<T, false>(g, st);
 }
 template hipError_t launch_gemm_nt<bf16_t>(const GemmArgs&, hipStream_t);
 template hipError_t launch_gemm_nt<float>(const GemmArgs&, hipStream_t);

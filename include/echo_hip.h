@@ -131,6 +131,8 @@ typedef struct {
   const void* res; int64_t ldres, res_bo, res_bi;
   const void* snake_alpha;
   int store_main, swiglu;
+  int cfg;                       /* tile configuration 0..4 (csrc/gemm.hip TileCfg table) */
+  int ksplit; void* ws; int64_t ws_bytes;   /* split-K: fp32 workspace of ksplit * roundup(M,256) * Npad * 4 bytes */
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,

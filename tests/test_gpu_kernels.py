@@ -287,3 +287,39 @@ def test_transpose_heads(dt, HD):
     ref = v[:, :H * HD].reshape(B, S, H, HD).permute(0, 2, 3, 1)
     assert torch.equal(vt[..., :S], ref)
     assert bool((vt[..., S:] == 0).all())
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("ksplit", [1, 2, 4])
+def test_gemm_all_tile_configs_and_splitk(cfg, ksplit):
+    """Every tile configuration / pipeline depth / split-K factor gives the same result (bf16 epilogue, fp32 taps, SwiGLU)."""
+    M, N, K = 300, 384, 512
+    A, W = rnd(M, K, dtype=torch.bfloat16), U.pad_rows(rnd(N, K, dtype=torch.bfloat16, seed=1))
+    bias, cs = rnd(N, dtype=torch.bfloat16, seed=2), rnd(N, dtype=torch.bfloat16, seed=3)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=4)
+    out = res.clone()
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias, colscale=cs, res=out, ldres=N, cfg=cfg, ksplit=ksplit)
+    y = (A.float() @ W[:N].float().T + bias.float()).bfloat16()
+    y = ((y.float() * cs.float()).bfloat16().float() + res.float()).bfloat16()
+    U.bf16_close(out, y, ulps=2.0, atol=2e-3)
+    # SwiGLU
+    F = 192
+    w1, w3 = rnd(F, K, dtype=torch.bfloat16, seed=5, scale=0.1), rnd(F, K, dtype=torch.bfloat16, seed=6, scale=0.1)
+    Wp = U.pack_swiglu(w1, w3)
+    o2 = torch.zeros((M, F), dtype=torch.bfloat16, device=DEV)
+    U.gemm(A, Wp, o2, M=M, N=2 * F, K=K, lda=K, ldw=K, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=cfg, ksplit=ksplit)
+    a = (A.float() @ w1.float().T).bfloat16()
+    b = (A.float() @ w3.float().T).bfloat16()
+    U.bf16_close(o2, (torch.nn.functional.silu(a.float()).bfloat16().float() * b.float()).bfloat16(), ulps=2.0, atol=2e-3)
+    # fp32 dilated conv through the taps loop
+    T_, Ci, Co, k, dil = 333, 64, 96, 7, 3
+    x = rnd(1, Ci, T_)
+    w = rnd(Co, Ci, k, seed=7, scale=0.1)
+    ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double(), ((k - 1) * dil, 0)), w.double(), dilation=dil)[0].T
+    xcl = torch.zeros((64 + T_, Ci), device=DEV)
+    xcl[64:] = x[0].T
+    Wg = U.pad_rows(w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous())
+    o3 = torch.zeros((T_, Co), device=DEV)
+    U.gemm(xcl, Wg, o3, M=T_, N=Co, K=Ci, lda=Ci, ldw=k * Ci, ldc=Co, taps=k, tap_base=-(k - 1) * dil, tap_shift=dil,
+           a_offset_elems=64 * Ci, cfg=cfg, ksplit=ksplit)
+    assert (o3.double() - ref).abs().max().item() < 1e-4
