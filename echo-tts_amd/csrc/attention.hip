@@ -20,16 +20,17 @@
 // of 8 consecutive keys = exactly the B-operand fragments of the following Oᵀ += Vᵀ·Pᵀ MFMAs, so
 // P never leaves registers (cdna_hip_programming.md §3 "accumulator tile as the next operand").
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int QT = 128;      // queries per workgroup
 constexpr int KT = 64;       // keys per tile
 constexpr int HD = 128;
+constexpr float RESCALE_LOG2 = 4.0f;   // deferred-rescale threshold, in log2 units of the softmax argument
 constexpr int K_TILE_BYTES = KT * HD * 2;    // 16 KiB, rows of 256 B
 constexpr int V_TILE_BYTES = HD * KT * 2;    // 16 KiB, rows of 128 B
-constexpr int STAGE = K_TILE_BYTES + V_TILE_BYTES;
-constexpr int SMEM = 2 * STAGE;
+constexpr int SMEM = 2 * (K_TILE_BYTES + V_TILE_BYTES);
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -38,20 +39,36 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
-  bf16x8 r;
+  f32x8 v;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(s[base + j]);
-  return r;
+  for (int j = 0; j < 8; ++j) v[j] = s[base + j];
+  return __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hbf16x8));   // 4 x v_cvt_pk_bf16_f32
 }
 
-template <bool CAUSAL>
-__global__ void __launch_bounds__(256, 2) attn_kernel(const AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// tile cursor carrying its segment's operands in scalar registers (refreshed only when the segment changes)
+struct TileIt { int seg, tile, nk; const char* kb; long kld; const char* vb; long vld; const float* bias; };
+struct LaneBase { const char* k[4]; const char* v[4]; };   // per-lane DMA source bases of a segment (k: + lane chunk, v: + d row & chunk)
+
+// Software-pipelined by one tile: the Sᵀ = K·Qᵀ MFMAs of tile t+1 are issued before the softmax (VALU) of tile t
+// so the two overlap inside one wave; K tiles therefore run one tile ahead of V tiles in the LDS rings.
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <bool CAUSAL, bool BIAS, bool PROF>
+__global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = blockIdx.z, head = blockIdx.y;
   const int qbase = blockIdx.x * QT;
   const int fr = lane & 31, fh = lane >> 5;
-  int q = qbase + wid * 32 + fr;
+  const int q = qbase + wid * 32 + fr;
   const bool q_ok = q < p.S;
   const int qc = q_ok ? q : p.S - 1;
 
@@ -63,8 +80,8 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(const AttnArgs p) {
     for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
   }
 
-  // ---- per-segment tile counts (wave-uniform)
-  const int q_hi = min(qbase + QT, p.S) - 1;  // last query of this workgroup
+  // ---- per-segment key counts (wave-uniform); explicit selects instead of runtime-indexed arrays
+  const int q_hi = min(qbase + QT, p.S) - 1;
   auto seg_keys = [&](int s) -> int {
     if (s >= p.nseg) return 0;
     int nk = p.seg[s].nkeys[row];
@@ -72,146 +89,276 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(const AttnArgs p) {
     return nk < 0 ? 0 : nk;
   };
   const int nk0 = seg_keys(0), nk1 = seg_keys(1), nk2 = seg_keys(2), nk3 = seg_keys(3);
-  // explicit selects instead of runtime-indexed arrays (those would live in scratch)
   auto NK = [&](int s) -> int { return s == 0 ? nk0 : s == 1 ? nk1 : s == 2 ? nk2 : s == 3 ? nk3 : 0; };
   auto NT = [&](int s) -> int { return (NK(s) + KT - 1) / KT; };
   const int total_tiles = NT(0) + NT(1) + NT(2) + NT(3);
-
-  // ---- staging roles: wave w issues K pieces 4w..4w+3 (4 keys x 256 B each) and V pieces (8 d-rows x 128 B)
-  const int k_row_in_piece = lane >> 4, k_slot = lane & 15;
-  const int v_row_in_piece = lane >> 3, v_slot = lane & 7;
-
-  auto stage = [&](int buf, int seg, int tile) {
-    const AttnSeg& sg = p.seg[seg];
-    const int kvrow = sg.kv_mod ? row % sg.kv_mod : row;
-    const int nk = NK(seg);
-    const int k0 = tile * KT;
-    char* kb = smem + buf * STAGE + wid * 4096;
-    char* vb = smem + buf * STAGE + K_TILE_BYTES + wid * 4096;
-    const char* kbase = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
-    const char* vbase = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
+  // ---- per-segment operands resolved ONCE into scalar registers (indexing the kernel-argument struct inside the tile
+  // loop costs a chain of s_load + s_waitcnt per use: measured 1800 cycles per tile)
+  const char* kb_[4]; const char* vb_[4]; long kld_[4], vld_[4]; const float* bias_[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (wid * 4 + i) * 4 + k_row_in_piece;       // key row inside the tile
-      int key = k0 + r;
-      key = key < nk ? key : nk - 1;                           // stay inside the valid rows
-      const int chunk = k_slot ^ (r & 15);
-      glds16(kbase + ((long)key * sg.k_ld) * 2 + chunk * 16, kb + i * 1024);
+  for (int sgi = 0; sgi < 4; ++sgi) {
+    kb_[sgi] = nullptr; vb_[sgi] = nullptr; kld_[sgi] = 0; vld_[sgi] = 0; bias_[sgi] = nullptr;
+    if (sgi < p.nseg) {
+      const AttnSeg& sg = p.seg[sgi];
+      const int kvrow = sg.kv_mod ? row % sg.kv_mod : row;
+      kb_[sgi] = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
+      vb_[sgi] = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
+      kld_[sgi] = sg.k_ld * 2; vld_[sgi] = sg.vt_ld * 2;
+      bias_[sgi] = sg.bias ? sg.bias + (long)kvrow * sg.bias_row_stride : nullptr;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = (wid * 4 + i) * 8 + v_row_in_piece;
-      const int chunk = v_slot ^ ((d >> 1) & 7);
-      glds16(vbase + ((long)d * sg.vt_ld + k0) * 2 + chunk * 16, vb + i * 1024);
+  }
+#define SEL4(arr, s) ((s) == 0 ? arr[0] : (s) == 1 ? arr[1] : (s) == 2 ? arr[2] : arr[3])
+  auto enter_seg = [&](TileIt& it, int seg) {   // rare: only at segment boundaries
+    it.seg = seg; it.tile = 0; it.nk = NK(seg);
+    it.kb = SEL4(kb_, seg); it.kld = SEL4(kld_, seg); it.vb = SEL4(vb_, seg); it.vld = SEL4(vld_, seg); it.bias = SEL4(bias_, seg);
+  };
+  auto advance = [&](TileIt it) -> TileIt {
+    ++it.tile;
+    if (it.tile * KT >= it.nk) {
+      int sgn = it.seg + 1;
+      while (sgn < 4 && NK(sgn) == 0) ++sgn;
+      if (sgn < 4) enter_seg(it, sgn); else --it.tile;   // stay on the last tile
     }
+    return it;
   };
 
-  // running state; scores are kept in the log2 domain (scale * log2(e) folded in)
-  const float c = p.scale * 1.4426950408889634f;
-  float m_i = -1e30f, l_i = 0.0f;
+  const int k_row_in_piece = lane >> 4, k_slot = lane & 15;
+  const int v_row_in_piece = lane >> 3, v_slot = lane & 7;
+  char* const kring = smem;
+  char* const vring = smem + 2 * K_TILE_BYTES;
+  // lane-constant parts of the DMA source offsets
+  int k_r[4], k_c[4], v_d[4], v_c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k_r[i] = (wid * 4 + i) * 4 + k_row_in_piece;
+    k_c[i] = (k_slot ^ (k_r[i] & 15)) << 4;
+    v_d[i] = (wid * 4 + i) * 8 + v_row_in_piece;
+    v_c[i] = (v_slot ^ ((v_d[i] >> 1) & 7)) << 4;
+  }
+
+  // DMA source addresses of one K / V tile (4 pieces per wave each); issue is separate so that the pieces can be
+  // spread between the MFMAs (a burst of 8 LDS-DMA instructions blocks the wave for ~1800 cycles: measured)
+  auto k_src = [&](const TileIt& it, const char* (&src)[4]) {
+    const int k0 = it.tile * KT;
+    const int last = it.nk - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = min(k0 + k_r[i], last);
+      src[i] = it.kb + k_c[i] + (long)key * it.kld;
+    }
+  };
+  auto v_src = [&](const TileIt& it, const char* (&src)[4]) {
+    const char* vbase = it.vb + it.tile * (KT * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) src[i] = vbase + v_c[i] + (long)v_d[i] * it.vld;
+  };
+  auto stage_k = [&](int slot, TileIt it) {
+    const char* src[4];
+    k_src(it, src);
+    char* kb = kring + slot * K_TILE_BYTES + wid * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(src[i], kb + i * 1024);
+  };
+  auto stage_v = [&](int slot, TileIt it) {
+    const char* src[4];
+    v_src(it, src);
+    char* vb = vring + slot * V_TILE_BYTES + wid * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(src[i], vb + i * 1024);
+  };
+
+  const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped
+  const int sw_v = (lane >> 1) & 7;
+
+  const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in the log2 domain
+  float m_i = -1e30f, l_i = 0.0f;                   // running max of the RAW scores, running denominator
   f32x16 o[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
 
-  // LDS fragment addresses
-  const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // swap bits 2 and 3
-  const int sw_v = (lane >> 1) & 7;
+  // K fragments of one 32-key sub-tile: 8 x ds_read_b128 into distinct registers (latency overlaps the MFMAs before)
+  auto load_k = [&](const char* sk, int ks, bf16x8 (&kf)[8]) {
+    const int krow = ks * 32 + pi_row;
+    const char* kr = sk + krow * 256;
+    const int sw_k = krow & 15;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kr + (((2 * kk + fh) ^ sw_k) << 4));
+  };
+  auto load_v = [&](const char* sv, int grp, bf16x8 (&vf)[4]) {   // grp = 2*ks + st: keys 16*grp .. 16*grp+15
+    const int chunk = 2 * grp + fh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) vf[d] = *(const bf16x8*)(sv + (d * 32 + fr) * 128 + ((chunk ^ sw_v) << 4));
+  };
 
-  int seg = 0, tile = 0;
-  while (seg < 4 && NT(seg) == 0) ++seg;
-  if (total_tiles > 0) stage(0, seg, 0);
-  for (int it = 0; it < total_tiles; ++it) {
-    __syncthreads();
-    // next tile
-    int nseg_ = seg, ntile = tile + 1;
-    if (ntile >= NT(seg)) { ntile = 0; ++nseg_; while (nseg_ < 4 && NT(nseg_) == 0) ++nseg_; }
-    if (it + 1 < total_tiles) stage((it + 1) & 1, nseg_, ntile);
-
-    const char* sk = smem + (it & 1) * STAGE;
-    const char* sv = sk + K_TILE_BYTES;
-    const int nk = NK(seg);
-    const int k0 = tile * KT;
-
-    // ---- Sᵀ (64 keys x 32 queries per wave)
-    f32x16 s[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[ks][r] = 0.0f;
-      const int krow = ks * 32 + pi_row;
-      const char* kr = sk + krow * 256;
-      const int sw_k = krow & 15;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8 kf = *(const bf16x8*)(kr + (((2 * kk + fh) ^ sw_k) << 4));
-        s[ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[ks], 0, 0, 0);
-      }
-    }
-
-    // ---- scale, mask, online softmax.  Register r of s[ks] is key k0 + 32ks + 16(r>>3) + 8fh + (r&7).
-    const AttnSeg& sg = p.seg[seg];
-    const bool need_mask = (k0 + KT > nk) || (sg.bias != nullptr) || (CAUSAL && (k0 + KT - 1 > qbase + wid * 32));
-    float mx = -INFINITY;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[ks][r] *= c;
-    if (need_mask) {
-      const float* bias = sg.bias ? sg.bias + (long)(sg.kv_mod ? row % sg.kv_mod : row) * sg.bias_row_stride : nullptr;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + 32 * ks + 16 * (r >> 3) + 8 * fh + (r & 7);
-          bool ok = key < nk;
-          if (CAUSAL) ok = ok && (key <= q);
-          float x = s[ks][r];
-          if (bias && ok) x += bias[key] * 1.4426950408889634f;
-          s[ks][r] = ok ? x : -INFINITY;
-        }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ks][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-    float rs = 0.0f;
+  // masks tile `it` in place (register r of s[ks] is key k0 + 32ks + 16(r>>3) + 8fh + (r&7)); rare path
+  auto apply_mask = [&](f32x16 (&s)[2], TileIt it) {
+    const int nk = it.nk, k0 = it.tile * KT;
+    const float* bias = it.bias;
+    const float inv_scale = 1.0f / p.scale;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[ks][r] - m_new);
-        s[ks][r] = pv;
-        rs += pv;
+        const int key = k0 + 32 * ks + 16 * (r >> 3) + 8 * fh + (r & 7);
+        bool ok = key < nk;
+        if (CAUSAL) ok = ok && (key <= q);
+        float x = s[ks][r];
+        if (BIAS) { if (bias) x += bias[ok ? key : 0] * inv_scale; }   // bias is added to the scaled score in the reference
+        s[ks][r] = ok ? x : -INFINITY;
       }
-    rs += __shfl_xor(rs, 32, 64);
-    l_i = l_i * alpha + rs;
-    m_i = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+  };
+  auto tile_needs_mask = [&](TileIt it) -> bool {
+    const int k0 = it.tile * KT;
+    return (k0 + KT > it.nk) || (BIAS && it.bias != nullptr) || (CAUSAL && (k0 + KT - 1 > qbase + wid * 32));
+  };
 
-    // ---- Oᵀ += Vᵀ · Pᵀ : 4 k-steps of 16 keys, 4 d sub-tiles of 32
+  // One pipeline step in a single basic block: Sᵀ(t+1) = K(t+1)·Qᵀ (16 MFMAs) interleaved with the first half of
+  // softmax(t) (row max, exp2, row sum: VALU), then the O rescale (rare) and Oᵀ += Vᵀ(t)·Pᵀ(t) (16 MFMAs).
+  // (on the last tile the "next" K slot holds a stale but valid tile: its Sᵀ is computed and dropped, which keeps this
+  // block free of branches and the kernel small enough for the instruction cache)
+  //
+  // MFMA / VALU balance per tile and wave: 32 MFMAs (16 Sᵀ(t+1) + 16 PV(t)) and 32 exponentials.  One exp chain
+  // (accvgpr read, fma, v_exp, add) costs ~20 issue cycles and hides in one 32-cycle MFMA shadow, so the source order
+  // pairs them: Sᵀ MFMAs with the exps of keys 0..31, the first 8 PV MFMAs (keys 0..31) with the exps of keys 32..63.
+  auto compute = [&](f32x16 (&scur)[2], f32x16 (&snext)[2], const char* sk_next, const char* sv,
+                     const char* (&ksrc)[4], char* kdst, const char* (&vsrc)[4], char* vdst) {
+    bf16x8 kf0[8], kf1[8], vf[4][4];
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (PROF) c0 = stamp();
+    load_k(sk_next, 0, kf0);
+    load_k(sk_next, 1, kf1);
+    load_v(sv, 0, vf[0]);
+    load_v(sv, 1, vf[1]);
+    // keep the score tile in architectural VGPRs: every softmax VALU op on an AGPR value costs an extra v_accvgpr_read
+    asm volatile("" : "+v"(scur[0]), "+v"(scur[1]));
+    // row max of tile t, new running max, O rescale (rare after the first tiles)
+    float mx = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pf = pack8(s[ks], 8 * st);
-        const int chunk = 4 * ks + 2 * st + fh;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, scur[ks][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // Deferred rescale (cdna_hip_programming.md T13): the reference point m_i only moves when some row's maximum grew
+    // by more than 2^RESCALE_LOG2; until then P = exp2((s - m_i) c) may exceed 1 (at most 2^RESCALE_LOG2), which costs
+    // no precision (bf16 is floating point, l and O accumulate in fp32).  With 32 rows per wave the undeferred test
+    // fires on almost every tile and the O rescale (64 accumulator registers) dominated the tile.
+    const float m_new = fmaxf(m_i, mx);
+    if (__any((m_new - m_i) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+      l_i *= alpha;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const bf16x8 vf = *(const bf16x8*)(sv + (d * 32 + fr) * 128 + ((chunk ^ sw_v) << 4));
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      m_i = m_new;
+    }
+    const float mc = m_i * c;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { snext[0][r] = 0.0f; snext[1][r] = 0.0f; }
+    if (PROF) c1 = stamp();
+    // sched_barrier(0) pins one {MFMA, its VALU shadow work, at most one DMA piece} group after the other: left alone,
+    // hipcc hoists all 8 LDS-DMA pieces into one burst (which blocks the wave) and clusters the MFMAs at the end.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      snext[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], snext[0], 0, 0, 0);
+      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[0][kk], c, -mc)); scur[0][kk] = pv; rs += pv; }
+      if (kk & 1) glds16(ksrc[kk >> 1], kdst + (kk >> 1) * 1024);   // K(t+2): one DMA piece every second MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      snext[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], snext[1], 0, 0, 0);
+      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[0][8 + kk], c, -mc)); scur[0][8 + kk] = pv; rs += pv; }
+      if (kk & 1) glds16(vsrc[kk >> 1], vdst + (kk >> 1) * 1024);   // V(t+1)
+      if (kk == 3) load_v(sv, 2, vf[2]);
+      if (kk == 5) load_v(sv, 3, vf[3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" : "+v"(snext[0]), "+v"(snext[1]));
+    if (PROF) c2 = stamp();
+    // Oᵀ += Vᵀ·Pᵀ: groups of 16 keys; groups 0,1 (keys 0..31) overlap the exps of keys 32..63
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const bf16x8 pf = pack8(scur[0], 8 * g);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g][d], pf, o[d], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 8 * g + 2 * d + e;
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[1][r], c, -mc)); scur[1][r] = pv; rs += pv;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    seg = nseg_; tile = ntile;
+    }
+#pragma unroll
+    for (int g = 2; g < 4; ++g) {
+      const bf16x8 pf = pack8(scur[1], 8 * (g - 2));
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g][d], pf, o[d], 0, 0, 0);
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_i += rs;
+    if (PROF) { c3 = stamp(); pt[4] += c1 - c0; pt[5] += c2 - c1; pt[6] += c3 - c2; }
+  };
+
+  if (total_tiles > 0) {
+    TileIt it0;
+    {
+      int s0 = 0;
+      while (s0 < 3 && NK(s0) == 0) ++s0;
+      enter_seg(it0, s0);
+    }
+    TileIt it1 = advance(it0);
+    stage_k(0, it0);
+    stage_v(0, it0);
+    if (total_tiles > 1) stage_k(1, it1);
+    __syncthreads();   // vmcnt(0) + barrier
+    f32x16 sa[2], sb[2];
+    {
+      bf16x8 kf0[8], kf1[8];
+      load_k(kring, 0, kf0);
+      load_k(kring, 1, kf1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[0][r] = 0.0f; sa[1][r] = 0.0f; }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) sa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], sa[0], 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) sa[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], sa[1], 0, 0, 0);
+    }
+    TileIt it_cur = it0, it_nxt = it1, it_nn = advance(it1);
+    // tile t is in `sa`; Sᵀ of tile t+1 is produced into `sb` and moved over at the end of the step
+#pragma unroll 1
+    for (int t = 0; t < total_tiles; ++t) {
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (PROF) t0 = stamp();
+      __syncthreads();   // K(t+1), V(t) landed; every wave finished QK(t) and PV(t-1)
+      if (PROF) t1 = stamp();
+      // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the iterators stay on the last
+      // tile: the redundant pieces land in slots nobody reads again (and are drained before the epilogue).
+      const char* ksrc[4]; const char* vsrc[4];
+      k_src(it_nn, ksrc);
+      v_src(it_nxt, vsrc);
+      char* kdst = kring + (t & 1) * K_TILE_BYTES + wid * 4096;
+      char* vdst = vring + ((t + 1) & 1) * V_TILE_BYTES + wid * 4096;
+      if (tile_needs_mask(it_cur)) apply_mask(sa, it_cur);
+      if (PROF) t2 = stamp();
+      compute(sa, sb, kring + ((t + 1) & 1) * K_TILE_BYTES, vring + (t & 1) * V_TILE_BYTES, ksrc, kdst, vsrc, vdst);
+      if (PROF) { const unsigned long long t3 = stamp(); pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += 1; }
+      sa[0] = sb[0]; sa[1] = sb[1];
+      it_cur = it_nxt; it_nxt = it_nn; it_nn = advance(it_nn);
+    }
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup ends
+  if (PROF && lane == 0) {
+    unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+    dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4]; dst[5] = pt[5]; dst[6] = pt[6];
+  }
   // ---- epilogue: lane holds O[q][32d + 8g + 4fh + 0..3]
   if (!q_ok) return;
   const float inv_l = 1.0f / l_i;
@@ -244,14 +391,22 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     if ((a.seg[s].vt_ld & 7) || (a.seg[s].k_ld & 7) || !a.seg[s].nkeys) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return e;
+    const void* ks[] = {(const void*)attn_kernel<false, false, false>, (const void*)attn_kernel<true, false, false>,
+                        (const void*)attn_kernel<false, true, false>, (const void*)attn_kernel<true, true, false>,
+                        (const void*)attn_kernel<false, false, true>};
+    for (const void* k : ks) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      if (e != hipSuccess) return e;
+    }
     attr_set = true;
   }
   dim3 grid((a.S + QT - 1) / QT, a.H, a.rows);
-  if (a.causal) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), SMEM, st, a);
-  else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), SMEM, st, a);
+  bool bias = false;
+  for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
+  if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(256), SMEM, st, a);   // s_memtime stamps
+  else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(256), SMEM, st, a);
+  else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(256), SMEM, st, a);
+  else if (bias) hipLaunchKernelGGL((attn_kernel<false, true, false>), grid, dim3(256), SMEM, st, a);
+  else hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(256), SMEM, st, a);
   return hipGetLastError();
 }

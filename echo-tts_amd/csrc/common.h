@@ -17,11 +17,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // ---------------------------------------------------------------- numeric traits
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  // round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  // plain cast = v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hbf16x2));
 }
 
 template <typename T> struct Num;
@@ -48,8 +53,8 @@ template <> struct Vec4<bf16_t> {
   }
   __device__ __forceinline__ static raw pack(const float* f) {
     raw r;
-    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    r.x = pack_bf16x2(f[0], f[1]);
+    r.y = pack_bf16x2(f[2], f[3]);
     return r;
   }
 };
@@ -118,6 +123,7 @@ struct AttnArgs {
   int nseg; AttnSeg seg[4];
   int causal;                   // only with nseg == 1 (encoder self-attention)
   float scale;
+  void* prof;                   // diagnostic: per-wave {barrier, issue, compute, tiles} cycle sums (s_memtime); nullptr in production
 };
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);
 

@@ -17,10 +17,10 @@ template <> struct Chunk8<bf16_t> {
   }
   __device__ __forceinline__ static void store(bf16_t* p, const float* f) {
     uint4 r;
-    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    r.x = pack_bf16x2(f[0], f[1]);
+    r.y = pack_bf16x2(f[2], f[3]);
+    r.z = pack_bf16x2(f[4], f[5]);
+    r.w = pack_bf16x2(f[6], f[7]);
     *(uint4*)p = r;
   }
 };

@@ -1379,7 +1379,7 @@ int echo_op_attention_bf16(const echo_attn_desc* d, void* stream) {
   a.Q = (const bf16_t*)d->Q; a.q_ld = d->q_ld; a.q_row_stride = d->q_row_stride;
   a.O = (bf16_t*)d->O; a.o_ld = d->o_ld; a.o_row_stride = d->o_row_stride;
   a.G = (const bf16_t*)d->G; a.g_ld = d->g_ld; a.g_row_stride = d->g_row_stride;
-  a.S = d->S; a.H = d->H; a.rows = d->rows; a.nseg = d->nseg; a.causal = d->causal; a.scale = d->scale;
+  a.S = d->S; a.H = d->H; a.rows = d->rows; a.nseg = d->nseg; a.causal = d->causal; a.scale = d->scale; a.prof = d->prof;
   for (int s = 0; s < d->nseg && s < 4; ++s) {
     a.seg[s].K = (const bf16_t*)d->seg[s].K; a.seg[s].k_ld = d->seg[s].k_ld; a.seg[s].k_row_stride = d->seg[s].k_row_stride;
     a.seg[s].k_head_stride = d->seg[s].k_head_stride;

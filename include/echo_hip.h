@@ -148,6 +148,7 @@ typedef struct {
   void* O; int64_t o_ld, o_row_stride;
   const void* G; int64_t g_ld, g_row_stride;
   int S, H, rows, nseg; echo_attn_seg seg[4]; int causal; float scale;
+  void* prof;                    /* diagnostic build only: (workgroups*4, 4) uint64 cycle sums; NULL normally */
 } echo_attn_desc;
 int echo_op_attention_bf16(const echo_attn_desc* d, void* stream);
 
