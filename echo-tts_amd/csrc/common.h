@@ -101,6 +101,13 @@ struct GemmArgs {
   int cfg;                      // tile configuration (gemm.hip TileCfg table), 0 = 128x128x2 stages
   int ksplit;                   // > 1: split K over blockIdx.z, fp32 partial slabs in ws, reduce kernel applies the tail
   void* ws; long ws_bytes;
+  // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the
+  // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
+  // position pos0 + (m % qkv_S); the v section is written TRANSPOSED to vt[(m / S)][h][d][m % S]; gate is stored as is.
+  int qkv_mode, qkv_D, qkv_S, rope_heads, pos0;
+  float qk_eps;
+  const void* qk_w; const void* rope;
+  void* vt; long vt_ld, vt_row_stride;
 };
 int gemm_tile_m(int cfg);
 int gemm_num_cfgs();

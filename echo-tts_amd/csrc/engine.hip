@@ -220,7 +220,7 @@ struct Engine : EngineBase {
   template <typename U>
   int plan_gemm(GemmArgs& g, hipStream_t st) {
     const int KEu = 128 / (int)sizeof(U);
-    const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U)};
+    const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U), g.qkv_mode};
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan best;
@@ -231,14 +231,14 @@ struct Engine : EngineBase {
         GemmArgs t = g;
         const long out_el = ((long)g.M + 256) * (g.ldc > g.Npad ? g.ldc : g.Npad);
         CK(b_tune_c.reserve((size_t)out_el * sizeof(U) * (g.nbatch > 1 ? 1 : 1)));
-        t.C = b_tune_c.p; t.C2 = nullptr; t.res = nullptr; t.snake_alpha = nullptr; t.store_main = 1; t.colscale = nullptr; t.bias = nullptr;
+        t.C = b_tune_c.p; t.C2 = nullptr; t.res = nullptr; t.snake_alpha = nullptr; t.store_main = 1; t.colscale = nullptr; t.bias = nullptr; t.qkv_mode = 0;
         if (g.nbatch > 1) { t.nbatch = 1; t.nbi = 1; }
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         float best_ms = 1e30f;
         for (int cfg = 0; cfg < gemm_num_cfgs(); ++cfg) {
           for (int ksp = 1; ksp <= 8; ksp *= 2) {
-            if (ksp > 1 && (g.nbatch > 1 || nk / ksp < 4 || t128 * ksp > 1024)) continue;
+            if (ksp > 1 && (g.nbatch > 1 || g.qkv_mode || nk / ksp < 4 || t128 * ksp > 1024)) continue;
             t.cfg = cfg; t.ksplit = ksp;
             if (ksp > 1) {
               const long need = (long)ksp * (((long)g.M + 255) / 256 * 256) * g.Npad * 4;
@@ -556,9 +556,16 @@ struct Engine : EngineBase {
     T *x = b_ex.as<T>(), *xn = b_exn.as<T>(), *qkvg = b_eqkvg.as<T>(), *vt = b_evt.as<T>(), *ao = b_eattn.as<T>(), *hh = b_eh.as<T>();
     for (int i = 0; i < e.L; ++i) {
       CK(launch_norm<T>(NORM_RMS_W, x, d, xn, d, M, d, cfg.norm_eps, e.an[i], nullptr, st));
-      CKI(run(G(xn, d, e.wqkvg[i], d, qkvg, 4 * d, M, 4 * d, d), st));
-      CK(launch_headnorm_rope_nt<T>(qkvg, 4 * d, d, 2, M, Tn, H, e.qkn + (long)i * 2 * d, d, cfg.norm_eps, 1, H, rope, 0, 1, st));
-      CK(launch_transpose_heads<T>(qkvg + 2 * d, 4 * d, vt, Tpad, (long)d * Tpad, B, Tn, H, 128, st));
+      if (d % 256 == 0) {
+        GemmArgs g = G(xn, d, e.wqkvg[i], d, qkvg, 4 * d, M, 4 * d, d);
+        g.qkv_mode = 1; g.qkv_D = d; g.qkv_S = Tn; g.rope_heads = H; g.pos0 = 0; g.qk_eps = cfg.norm_eps;
+        g.qk_w = e.qkn + (long)i * 2 * d; g.rope = rope; g.vt = vt; g.vt_ld = Tpad; g.vt_row_stride = (long)d * Tpad;
+        CKI(run(g, st));
+      } else {
+        CKI(run(G(xn, d, e.wqkvg[i], d, qkvg, 4 * d, M, 4 * d, d), st));
+        CK(launch_headnorm_rope_nt<T>(qkvg, 4 * d, d, 2, M, Tn, H, e.qkn + (long)i * 2 * d, d, cfg.norm_eps, 1, H, rope, 0, 1, st));
+        CK(launch_transpose_heads<T>(qkvg + 2 * d, 4 * d, vt, Tpad, (long)d * Tpad, B, Tn, H, 128, st));
+      }
       SegDesc sg = self_seg_proto;
       sg.K = qkvg + d; sg.k_ld = 4 * d; sg.k_row_stride = (long)Tn * 4 * d;
       sg.Vt = vt; sg.vt_ld = Tpad; sg.vt_row_stride = (long)d * Tpad;
@@ -777,9 +784,17 @@ struct Engine : EngineBase {
       const T* ma = modrow + (long)(2 * l) * 3 * D;
       const T* mm = modrow + (long)(2 * l + 1) * 3 * D;
       CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, ma + D, ma, st));
-      CKI(run(G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D), st));
-      CK(launch_headnorm_rope_nt<T>(qkvg, 4 * D, D, 2, M, S, H, qkn + (long)l * 2 * D, D, cfg.norm_eps, 1, H / 2, rope, start_pos, 1, st));
-      CK(launch_transpose_heads<T>(qkvg + 2 * D, 4 * D, vts, Sp, (long)D * Sp, rows, S, H, 128, st));
+      if (D % 256 == 0) {
+        // one launch: projection + q/k head RMSNorm + half-head RoPE + transposed V (gemm.hip fused QKV epilogue)
+        GemmArgs g = G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D);
+        g.qkv_mode = 1; g.qkv_D = D; g.qkv_S = S; g.rope_heads = H / 2; g.pos0 = start_pos; g.qk_eps = cfg.norm_eps;
+        g.qk_w = qkn + (long)l * 2 * D; g.rope = rope; g.vt = vts; g.vt_ld = Sp; g.vt_row_stride = (long)D * Sp;
+        CKI(run(g, st));
+      } else {
+        CKI(run(G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D), st));
+        CK(launch_headnorm_rope_nt<T>(qkvg, 4 * D, D, 2, M, S, H, qkn + (long)l * 2 * D, D, cfg.norm_eps, 1, H / 2, rope, start_pos, 1, st));
+        CK(launch_transpose_heads<T>(qkvg + 2 * D, 4 * D, vts, Sp, (long)D * Sp, rows, S, H, 128, st));
+      }
       SegDesc sg[4];
       sg[0].which = 0; sg[0].maxk = S; sg[0].K = qkvg + D; sg[0].k_ld = 4 * D; sg[0].k_row_stride = (long)S * 4 * D;
       sg[0].Vt = vts; sg[0].vt_ld = Sp; sg[0].vt_row_stride = (long)D * Sp;

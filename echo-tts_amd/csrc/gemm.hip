@@ -305,6 +305,68 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
         const f32x4 b4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + 4 + q) ^ ml)) * 4);
         swiglu_tail<T>(p, m, j0, a4, b4, C);
       }
+    } else if (p.qkv_mode) {
+      const int D = p.qkv_D;
+      const int sec = (tile_n * BN) / D;           // the whole tile lies in one of q | k | v | gate (D % BN == 0)
+      if (sec == 2) {
+        // V section: transposed store, 8 consecutive tokens of one d per thread
+#pragma unroll 1
+        for (int idx = tid; idx < BN * 4; idx += CF::NT) {
+          const int col = idx % BN, sg = idx / BN;
+          const int m = mrow0 + 8 * sg;
+          if (m >= p.M) continue;
+          float v8[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int rw = 8 * sg + r;
+            v8[r] = Num<T>::rnd(slab[(rw * CPR + ((col >> 2) ^ rw)) * 4 + (col & 3)]);
+          }
+          const int hd = tile_n * BN + col - 2 * D;        // h * 128 + d
+          const int b = m / p.qkv_S, sidx = m - b * p.qkv_S;
+          T* dst = (T*)p.vt + (long)b * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
+          if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
+            *(typename Vec4<T>::raw*)dst = Vec4<T>::pack(v8);
+            *(typename Vec4<T>::raw*)(dst + 4) = Vec4<T>::pack(v8 + 4);
+          } else {
+            for (int r = 0; r < 8 && m + r < p.M; ++r) {
+              const int bb = (m + r) / p.qkv_S, ss = (m + r) - bb * p.qkv_S;
+              ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(v8[r]);
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
+          const int ml = idx / CPR, chunk = idx % CPR;
+          const int m = mrow0 + ml;
+          const int n0 = tile_n * BN + chunk * 4;
+          const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+          float y[4] = {Num<T>::rnd(a4[0]), Num<T>::rnd(a4[1]), Num<T>::rnd(a4[2]), Num<T>::rnd(a4[3])};
+          if (sec < 2) {
+            // 32 consecutive lanes hold the 128 columns of one (token, head): half-wave reduction of the squares
+            float ss = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float rs = rsqrtf(ss / 128.0f + p.qk_eps);
+            const int nd = n0 - sec * D;                   // h * 128 + d
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[i] = Num<T>::rnd(__fmul_rn(__fmul_rn(y[i], rs), vec_at<T>(p.qk_w, (long)sec * D + nd + i)));
+            if ((nd >> 7) < p.rope_heads) {
+              const int pos = p.pos0 + m % p.qkv_S;
+              const float2* rp = (const float2*)p.rope + (long)pos * 64 + ((nd & 127) >> 1);
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                const float2 cs = rp[pr];
+                const float a = y[2 * pr], bq = y[2 * pr + 1];
+                y[2 * pr] = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(bq, cs.y));
+                y[2 * pr + 1] = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(bq, cs.x));
+              }
+            }
+          }
+          if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
+        }
+      }
     } else {
 #pragma unroll 1
       for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
@@ -399,6 +461,8 @@ hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
       (g.ldc & 3) || g.cfg < 0 || g.cfg >= gemm_num_cfgs())
+    return hipErrorInvalidValue;
+  if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
     return hipErrorInvalidValue;
   if (g.ksplit > 1) {
     if (g.nbatch != 1 || !g.ws || g.ksplit > (g.K / KE) * g.taps) return hipErrorInvalidValue;
