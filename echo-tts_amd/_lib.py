@@ -64,7 +64,7 @@ class EchoGemmDesc(C.Structure):
                 ("res", vp), ("ldres", c_i64), ("res_bo", c_i64), ("res_bi", c_i64),
                 ("snake_alpha", vp),
                 ("store_main", C.c_int), ("swiglu", C.c_int),
-                ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64)]
+                ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int)]
 
 
 class EchoAttnSeg(C.Structure):

@@ -220,7 +220,7 @@ struct Engine : EngineBase {
   template <typename U>
   int plan_gemm(GemmArgs& g, hipStream_t st) {
     const int KEu = 128 / (int)sizeof(U);
-    const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U), g.qkv_mode};
+    const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U), g.qkv_mode, g.split3};
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan best;
@@ -1062,8 +1062,10 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
 
+  bool dac_split3 = getenv("ECHO_DAC_EXACT_FP32") ? atoi(getenv("ECHO_DAC_EXACT_FP32")) == 0 : true;
   int frun(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
+    g.split3 = dac_split3 ? 1 : 0;
     CKI(plan_gemm<float>(g, st));
     if (profiling) {
       if (gemm_events_used == gemm_events.size()) {
@@ -1381,7 +1383,7 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.bias = d->bias; g.bias_bo = d->bias_bo; g.bias_bi = d->bias_bi; g.vec_mod = d->vec_mod; g.div = d->div; g.act = d->act;
   g.colscale = d->colscale; g.res = d->res; g.ldres = d->ldres; g.res_bo = d->res_bo; g.res_bi = d->res_bi;
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
-  g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes;
+  g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
 }
 int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,

@@ -114,7 +114,11 @@ __device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, co
   *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + j0) = Vec4<T>::pack(o);
 }
 
-template <typename T, bool SWIGLU, typename CF>
+// SPLIT3 (fp32 only): every fp32 operand x is split in registers into bf16 hi = bf16(x), lo = bf16(x - hi) and the
+// product is evaluated as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (relative error ~2^-16 per
+// product, ~1e-5 on sums): 16/3 times the fp32-MFMA rate.  Used for the Fish S1-DAC decoder whose 1e-4 waveform
+// tolerance leaves three orders of magnitude of head room; the parity-mode DiT keeps the exact fp32 MFMA.
+template <typename T, bool SWIGLU, typename CF, bool SPLIT3>
 __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = KBYTES / (int)sizeof(T);
@@ -164,12 +168,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
   long a_off = (long)(it0 / kb_per_tap) * p.tap_shift * p.lda * (long)sizeof(T) + (long)kb * KBYTES;
   long w_off = (long)it0 * KBYTES;
 
-  auto stage = [&](int slot) {
-    char* base = smem + slot * CF::STAGE_BYTES + wid * (PPW * 1024);
+  // DMA of one stage: sources are resolved first (next_src), the PPW pieces are then issued one at a time between the
+  // MFMAs of the current tile (issue_piece): a burst of 8 LDS-DMA instructions blocks the wave for ~500-1800 cycles.
+  const char* nsrc[PPW];
+  char* ndst = nullptr;
+  auto next_src = [&](int slot) {
+    ndst = smem + slot * CF::STAGE_BYTES + wid * (PPW * 1024);
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(src[i] + (is_a[i] ? a_off : w_off), base + i * 1024);
+    for (int i = 0; i < PPW; ++i) nsrc[i] = src[i] + (is_a[i] ? a_off : w_off);
     a_off += KBYTES; w_off += KBYTES;
     if (++kb == kb_per_tap) { kb = 0; a_off += a_tap_bytes; }
+  };
+  auto stage = [&](int slot) {
+    next_src(slot);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(nsrc[i], ndst + i * 1024);
   };
 
   // ---- fragment read addresses
@@ -193,6 +206,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
   for (int s = 0; s < STAGES - 1; ++s)
     if (issued < nk) { stage(s); ++issued; }
 
+  constexpr int NMF = (Num<T>::is_bf16 ? 4 : 16) * TN * TM;   // MFMAs per K step and wave
   for (int it = 0; it < nk; ++it) {
     // tile `it` must have landed: allow (tiles still in flight - 1) * PPW younger DMA pieces to stay outstanding
     const int younger = issued - it - 1;
@@ -200,9 +214,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
     else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPW>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // every wave's pieces of tile `it` are in LDS; everyone finished reading tile it-1
-    if (issued < nk) { stage((it + STAGES - 1) % STAGES); ++issued; }
+    const bool more = issued < nk;   // wave-uniform
+    if (more) { next_src((it + STAGES - 1) % STAGES); ++issued; }
 
     const char* sa = smem + (it % STAGES) * CF::STAGE_BYTES;
+    int mf = 0, piece = 0;
+    // after every MFMA: issue the next DMA piece when due, then pin the order (sched_barrier) so that the pieces stay
+    // spread over the tile instead of being hoisted into one burst
+    auto after_mfma = [&]() {
+      ++mf;
+      if (piece < PPW && mf * PPW >= (piece + 1) * NMF) {
+        if (more) glds16(nsrc[piece], ndst + piece * 1024);
+        ++piece;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     if constexpr (Num<T>::is_bf16) {
       bf16x8 wf[2][TN], af[2][TM];
       auto load = [&](int kk, int b) {
@@ -219,8 +245,41 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm) {
             acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tn], af[kk & 1][tm], acc[tn][tm], 0, 0, 0);
+            after_mfma();
+          }
+      }
+    } else if constexpr (SPLIT3) {
+      // 32 floats per row and K step = two bf16 MFMA k-steps of 16; lane (fr, fh) needs floats 16kk + 8fh .. +7
+      auto split = [&](const char* rowp, int kk, bf16x8& hi, bf16x8& lo) {
+        const f32x4 x0 = *(const f32x4*)(rowp + (((4 * kk + 2 * fh) ^ sw) << 4));
+        const f32x4 x1 = *(const f32x4*)(rowp + (((4 * kk + 2 * fh + 1) ^ sw) << 4));
+        f32x8 x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = x0[i]; x[4 + i] = x1[i]; }
+        const hbf16x8 h = __builtin_convertvector(x, hbf16x8);
+        const f32x8 hf = __builtin_convertvector(h, f32x8);
+        const hbf16x8 l = __builtin_convertvector(x - hf, hbf16x8);
+        hi = __builtin_bit_cast(bf16x8, h);
+        lo = __builtin_bit_cast(bf16x8, l);
+      };
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 whi[TN], wlo[TN], ahi[TM], alo[TM];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) split(sa + w_row0 + t * 32 * KBYTES, kk, whi[t], wlo[t]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) split(sa + a_row0 + t * 32 * KBYTES, kk, ahi[t], alo[t]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[tn], ahi[tm], acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[tn], alo[tm], acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[tn], ahi[tm], acc[tn][tm], 0, 0, 0);
+            mf += 7; after_mfma();   // 3 bf16 MFMAs stand for 8 fp32 ones in the DMA-piece schedule (NMF counts fp32 MFMAs)
+          }
       }
     } else {
       f32x4 wf[2][TN], af[2][TM];
@@ -240,10 +299,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm) {
               acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fh ? wf[cc & 1][tn][2 * s + 1] : wf[cc & 1][tn][2 * s],
                                                                  fh ? af[cc & 1][tm][2 * s + 1] : af[cc & 1][tm][2 * s],
                                                                  acc[tn][tm], 0, 0, 0);
+              after_mfma();
+            }
       }
     }
   }
@@ -412,10 +473,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs p, in
   }
 }
 
-template <typename T, bool SW, typename CF>
+template <typename T, bool SW, typename CF, bool SPLIT3 = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<T, SW, CF>;
+  auto kern = gemm_nt_kernel<T, SW, CF, SPLIT3>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     if (e != hipSuccess) return e;
@@ -441,6 +502,17 @@ typedef TileCfg<128, 256, 2, 4, 3> Cfg4;   // 8 waves (64x64 each), 144 KiB, 2 t
 
 template <typename T, bool SW>
 hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
+  if constexpr (!Num<T>::is_bf16) {
+    if (g.split3) {
+      switch (g.cfg) {
+        case 1: return launch_cfg<T, SW, Cfg1, true>(g, st);
+        case 2: return launch_cfg<T, SW, Cfg2, true>(g, st);
+        case 3: return launch_cfg<T, SW, Cfg3, true>(g, st);
+        case 4: return launch_cfg<T, SW, Cfg4, true>(g, st);
+        default: return launch_cfg<T, SW, Cfg0, true>(g, st);
+      }
+    }
+  }
   switch (g.cfg) {
     case 1: return launch_cfg<T, SW, Cfg1>(g, st);
     case 2: return launch_cfg<T, SW, Cfg2>(g, st);

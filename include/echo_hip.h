@@ -133,6 +133,7 @@ typedef struct {
   int store_main, swiglu;
   int cfg;                       /* tile configuration 0..4 (csrc/gemm.hip TileCfg table) */
   int ksplit; void* ws; int64_t ws_bytes;   /* split-K: fp32 workspace of ksplit * roundup(M,256) * Npad * 4 bytes */
+  int split3;                    /* fp32 only: 3 x bf16 MFMA per product (hi/lo operand splitting), ~1e-5 relative error */
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,

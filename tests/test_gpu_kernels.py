@@ -323,3 +323,16 @@ def test_gemm_all_tile_configs_and_splitk(cfg, ksplit):
     U.gemm(xcl, Wg, o3, M=T_, N=Co, K=Ci, lda=Ci, ldw=k * Ci, ldc=Co, taps=k, tap_base=-(k - 1) * dil, tap_shift=dil,
            a_offset_elems=64 * Ci, cfg=cfg, ksplit=ksplit)
     assert (o3.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 4])
+def test_gemm_f32_split3_accuracy(cfg):
+    """fp32 GEMM on 3 bf16 MFMAs per product: relative error ~1e-5 of the exact result (used by the DAC decoder)."""
+    M, N, K = 300, 256, 1024
+    A = rnd(M, K)
+    W = U.pad_rows(rnd(N, K, seed=1))
+    out = torch.zeros((M, N), device=DEV)
+    U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, cfg=cfg, split3=1)
+    ref = A.double() @ W[:N].double().T
+    rel = ((out.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel < 3e-5, rel

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import gpu_util as U
 
-def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4), splits=(1, 2, 4, 8)):
+def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4), splits=(1, 2, 4, 8), split3=0):
     A = (torch.randn((M + 256, K), device="cuda") * 0.5).to(dtype)
     W = (torch.randn(((N + 255) // 256 * 256, K), device="cuda") * 0.05).to(dtype)
     C = torch.zeros((M, N if not swiglu else N // 2), dtype=dtype, device="cuda")
@@ -15,7 +15,7 @@ def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4
             nk = K // (64 if dtype == torch.bfloat16 else 32)
             if ks > 1 and nk // ks < 4:
                 continue
-            kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc, swiglu=swiglu, cfg=cfg, ksplit=ks, Npad=(N + 127) // 128 * 128)
+            kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc, swiglu=swiglu, cfg=cfg, ksplit=ks, Npad=(N + 127) // 128 * 128, split3=split3)
             for _ in range(2):
                 U.gemm(A, W, C, **kw)
             torch.cuda.synchronize()
@@ -44,3 +44,7 @@ if __name__ == "__main__":
     bench(4096, 4096, 4096, dtype=torch.float32, iters=3, splits=(1,))
     bench(20480, 768, 768, dtype=torch.float32, iters=5, splits=(1, 2))
     bench(163840, 384, 384, dtype=torch.float32, iters=3, splits=(1,))
+    print("--- fp32 with 3 x bf16 MFMA (split3)")
+    bench(4096, 4096, 4096, dtype=torch.float32, iters=3, splits=(1,), split3=1)
+    bench(20480, 768, 768, dtype=torch.float32, iters=5, splits=(1, 2), split3=1)
+    bench(163840, 384, 384, dtype=torch.float32, iters=3, splits=(1,), split3=1)
