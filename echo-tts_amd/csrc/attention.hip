@@ -30,7 +30,8 @@ constexpr int HD = 128;
 constexpr float RESCALE_LOG2 = 4.0f;   // deferred-rescale threshold, in log2 units of the softmax argument
 constexpr int K_TILE_BYTES = KT * HD * 2;    // 16 KiB, rows of 256 B
 constexpr int V_TILE_BYTES = HD * KT * 2;    // 16 KiB, rows of 128 B
-constexpr int SMEM = 2 * (K_TILE_BYTES + V_TILE_BYTES);
+constexpr int MERGE_BYTES = 4 * 64 * 66 * 4;   // final merge of the two key halves: 4 query blocks x 64 lanes x (64 O + m + l) floats
+constexpr int SMEM = MERGE_BYTES > 2 * (K_TILE_BYTES + V_TILE_BYTES) ? MERGE_BYTES : 2 * (K_TILE_BYTES + V_TILE_BYTES);
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -47,7 +48,6 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
 
 // tile cursor carrying its segment's operands in scalar registers (refreshed only when the segment changes)
 struct TileIt { int seg, tile, nk; const char* kb; long kld; const char* vb; long vld; const float* bias; };
-struct LaneBase { const char* k[4]; const char* v[4]; };   // per-lane DMA source bases of a segment (k: + lane chunk, v: + d row & chunk)
 
 // Software-pipelined by one tile: the Sᵀ = K·Qᵀ MFMAs of tile t+1 are issued before the softmax (VALU) of tile t
 // so the two overlap inside one wave; K tiles therefore run one tile ahead of V tiles in the LDS rings.
@@ -59,16 +59,22 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
+// Work split (one workgroup per CU, 8 waves = two per SIMD): wave w owns the 32 queries of block qb = w & 3 and,
+// inside every 64-key tile, the key half kh = w >> 2.  Each wave keeps its own online-softmax state (m, l, O) over its
+// key subset; the two halves of a query block are merged once through LDS after the loop.  Two co-resident waves per
+// SIMD let one wave's softmax VALU / LDS reads / DMA issue overlap the other's MFMAs, and every wave issues only 4 of
+// the tile's 32 LDS-DMA pieces.
 template <bool CAUSAL, bool BIAS, bool PROF>
-__global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
+__global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = wid & 3, kh = wid >> 2;
   const int row = blockIdx.z, head = blockIdx.y;
   const int qbase = blockIdx.x * QT;
   const int fr = lane & 31, fh = lane >> 5;
-  const int q = qbase + wid * 32 + fr;
+  const int q = qbase + qb * 32 + fr;
   const bool q_ok = q < p.S;
   const int qc = q_ok ? q : p.S - 1;
 
@@ -122,128 +128,102 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
     return it;
   };
 
-  const int k_row_in_piece = lane >> 4, k_slot = lane & 15;
-  const int v_row_in_piece = lane >> 3, v_slot = lane & 7;
   char* const kring = smem;
   char* const vring = smem + 2 * K_TILE_BYTES;
-  // lane-constant parts of the DMA source offsets
-  int k_r[4], k_c[4], v_d[4], v_c[4];
+  // DMA roles: a tile is 16 K pieces (4 keys x 256 B) + 16 V pieces (8 d-rows x 128 B); wave w issues pieces 2w, 2w+1 of each
+  int k_r[2], k_c[2], v_d[2], v_c[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    k_r[i] = (wid * 4 + i) * 4 + k_row_in_piece;
-    k_c[i] = (k_slot ^ (k_r[i] & 15)) << 4;
-    v_d[i] = (wid * 4 + i) * 8 + v_row_in_piece;
-    v_c[i] = (v_slot ^ ((v_d[i] >> 1) & 7)) << 4;
+  for (int i = 0; i < 2; ++i) {
+    k_r[i] = (wid * 2 + i) * 4 + (lane >> 4);
+    k_c[i] = ((lane & 15) ^ (k_r[i] & 15)) << 4;
+    v_d[i] = (wid * 2 + i) * 8 + (lane >> 3);
+    v_c[i] = ((lane & 7) ^ ((v_d[i] >> 1) & 7)) << 4;
   }
-
-  // DMA source addresses of one K / V tile (4 pieces per wave each); issue is separate so that the pieces can be
-  // spread between the MFMAs (a burst of 8 LDS-DMA instructions blocks the wave for ~1800 cycles: measured)
-  auto k_src = [&](const TileIt& it, const char* (&src)[4]) {
-    const int k0 = it.tile * KT;
-    const int last = it.nk - 1;
+  auto k_src = [&](const TileIt& it, const char* (&src)[2]) {
+    const int k0 = it.tile * KT, last = it.nk - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int key = min(k0 + k_r[i], last);
-      src[i] = it.kb + k_c[i] + (long)key * it.kld;
-    }
+    for (int i = 0; i < 2; ++i) src[i] = it.kb + k_c[i] + (long)min(k0 + k_r[i], last) * it.kld;
   };
-  auto v_src = [&](const TileIt& it, const char* (&src)[4]) {
+  auto v_src = [&](const TileIt& it, const char* (&src)[2]) {
     const char* vbase = it.vb + it.tile * (KT * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) src[i] = vbase + v_c[i] + (long)v_d[i] * it.vld;
+    for (int i = 0; i < 2; ++i) src[i] = vbase + v_c[i] + (long)v_d[i] * it.vld;
   };
-  auto stage_k = [&](int slot, TileIt it) {
-    const char* src[4];
+  auto stage_k = [&](int slot, const TileIt& it) {
+    const char* src[2];
     k_src(it, src);
-    char* kb = kring + slot * K_TILE_BYTES + wid * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(src[i], kb + i * 1024);
+    char* kb = kring + slot * K_TILE_BYTES + wid * 2048;
+    glds16(src[0], kb); glds16(src[1], kb + 1024);
   };
-  auto stage_v = [&](int slot, TileIt it) {
-    const char* src[4];
+  auto stage_v = [&](int slot, const TileIt& it) {
+    const char* src[2];
     v_src(it, src);
-    char* vb = vring + slot * V_TILE_BYTES + wid * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(src[i], vb + i * 1024);
+    char* vb = vring + slot * V_TILE_BYTES + wid * 2048;
+    glds16(src[0], vb); glds16(src[1], vb + 1024);
   };
 
   const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped
   const int sw_v = (lane >> 1) & 7;
+  const int krow = kh * 32 + pi_row;           // this wave's key sub-tile
+  const int sw_k = krow & 15;
 
   const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in the log2 domain
-  float m_i = -1e30f, l_i = 0.0f;                   // running max of the RAW scores, running denominator
+  float m_i = -1e30f, l_i = 0.0f;                   // reference point of the RAW scores, running denominator
   f32x16 o[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
 
-  // K fragments of one 32-key sub-tile: 8 x ds_read_b128 into distinct registers (latency overlaps the MFMAs before)
-  auto load_k = [&](const char* sk, int ks, bf16x8 (&kf)[8]) {
-    const int krow = ks * 32 + pi_row;
+  auto load_k = [&](const char* sk, bf16x8 (&kf)[8]) {
     const char* kr = sk + krow * 256;
-    const int sw_k = krow & 15;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kr + (((2 * kk + fh) ^ sw_k) << 4));
   };
-  auto load_v = [&](const char* sv, int grp, bf16x8 (&vf)[4]) {   // grp = 2*ks + st: keys 16*grp .. 16*grp+15
-    const int chunk = 2 * grp + fh;
+  auto load_v = [&](const char* sv, int st, bf16x8 (&vf)[4]) {   // keys 32kh + 16st .. +15 of the tile
+    const int chunk = 4 * kh + 2 * st + fh;
 #pragma unroll
     for (int d = 0; d < 4; ++d) vf[d] = *(const bf16x8*)(sv + (d * 32 + fr) * 128 + ((chunk ^ sw_v) << 4));
   };
 
-  // masks tile `it` in place (register r of s[ks] is key k0 + 32ks + 16(r>>3) + 8fh + (r&7)); rare path
-  auto apply_mask = [&](f32x16 (&s)[2], TileIt it) {
+  // masks this wave's half of tile `it` in place (register r is key k0 + 32kh + 16(r>>3) + 8fh + (r&7)); rare path
+  auto apply_mask = [&](f32x16& s, const TileIt& it) {
     const int nk = it.nk, k0 = it.tile * KT;
     const float* bias = it.bias;
     const float inv_scale = 1.0f / p.scale;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + 32 * ks + 16 * (r >> 3) + 8 * fh + (r & 7);
-        bool ok = key < nk;
-        if (CAUSAL) ok = ok && (key <= q);
-        float x = s[ks][r];
-        if (BIAS) { if (bias) x += bias[ok ? key : 0] * inv_scale; }   // bias is added to the scaled score in the reference
-        s[ks][r] = ok ? x : -INFINITY;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 32 * kh + 16 * (r >> 3) + 8 * fh + (r & 7);
+      bool ok = key < nk;
+      if (CAUSAL) ok = ok && (key <= q);
+      float x = s[r];
+      if (BIAS) { if (bias) x += bias[ok ? key : 0] * inv_scale; }   // bias is added to the scaled score in the reference
+      s[r] = ok ? x : -INFINITY;
+    }
   };
-  auto tile_needs_mask = [&](TileIt it) -> bool {
+  auto tile_needs_mask = [&](const TileIt& it) -> bool {
     const int k0 = it.tile * KT;
-    return (k0 + KT > it.nk) || (BIAS && it.bias != nullptr) || (CAUSAL && (k0 + KT - 1 > qbase + wid * 32));
+    return (k0 + KT > it.nk) || (BIAS && it.bias != nullptr) || (CAUSAL && (k0 + KT - 1 > qbase + qb * 32));
   };
 
-  // One pipeline step in a single basic block: Sᵀ(t+1) = K(t+1)·Qᵀ (16 MFMAs) interleaved with the first half of
-  // softmax(t) (row max, exp2, row sum: VALU), then the O rescale (rare) and Oᵀ += Vᵀ(t)·Pᵀ(t) (16 MFMAs).
-  // (on the last tile the "next" K slot holds a stale but valid tile: its Sᵀ is computed and dropped, which keeps this
-  // block free of branches and the kernel small enough for the instruction cache)
-  //
-  // MFMA / VALU balance per tile and wave: 32 MFMAs (16 Sᵀ(t+1) + 16 PV(t)) and 32 exponentials.  One exp chain
-  // (accvgpr read, fma, v_exp, add) costs ~20 issue cycles and hides in one 32-cycle MFMA shadow, so the source order
-  // pairs them: Sᵀ MFMAs with the exps of keys 0..31, the first 8 PV MFMAs (keys 0..31) with the exps of keys 32..63.
-  auto compute = [&](f32x16 (&scur)[2], f32x16 (&snext)[2], const char* sk_next, const char* sv,
-                     const char* (&ksrc)[4], char* kdst, const char* (&vsrc)[4], char* vdst) {
-    bf16x8 kf0[8], kf1[8], vf[4][4];
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    if (PROF) c0 = stamp();
-    load_k(sk_next, 0, kf0);
-    load_k(sk_next, 1, kf1);
-    load_v(sv, 0, vf[0]);
-    load_v(sv, 1, vf[1]);
-    // keep the score tile in architectural VGPRs: every softmax VALU op on an AGPR value costs an extra v_accvgpr_read
-    asm volatile("" : "+v"(scur[0]), "+v"(scur[1]));
-    // row max of tile t, new running max, O rescale (rare after the first tiles)
+  // One pipeline step: Sᵀ(t+1) for this wave's keys (8 MFMAs) paired with the first 8 exponentials of tile t, the first
+  // PV k-step (4 MFMAs) paired with the other 8, then the second PV k-step.  sched_barrier(0) pins each {MFMA, VALU
+  // shadow work, at most one DMA piece} group: left alone hipcc hoists the LDS-DMA pieces into a burst (which blocks
+  // the wave) and clusters the MFMAs.  On the last tile the "next" K slot holds a stale but valid tile whose Sᵀ is
+  // computed and dropped (no branch, small code).
+  auto compute = [&](f32x16& scur, f32x16& snext, const char* sk_next, const char* sv,
+                     const char* (&ksrc)[2], char* kdst, const char* (&vsrc)[2], char* vdst) {
+    bf16x8 kf[8], vf0[4], vf1[4];
+    load_k(sk_next, kf);
+    load_v(sv, 0, vf0);
+    load_v(sv, 1, vf1);
+    asm volatile("" : "+v"(scur));   // keep the score tile in architectural VGPRs (no v_accvgpr_read per VALU use)
     float mx = -INFINITY;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, scur[ks][r]);
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, scur[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // Deferred rescale (cdna_hip_programming.md T13): the reference point m_i only moves when some row's maximum grew
-    // by more than 2^RESCALE_LOG2; until then P = exp2((s - m_i) c) may exceed 1 (at most 2^RESCALE_LOG2), which costs
-    // no precision (bf16 is floating point, l and O accumulate in fp32).  With 32 rows per wave the undeferred test
-    // fires on almost every tile and the O rescale (64 accumulator registers) dominated the tile.
+    // deferred rescale (cdna_hip_programming.md T13): the reference point only moves when a row's maximum grew by
+    // more than 2^RESCALE_LOG2; P may then exceed 1 (bf16 is floating point; l and O accumulate in fp32)
     const float m_new = fmaxf(m_i, mx);
     if (__any((m_new - m_i) * c > RESCALE_LOG2)) {
       const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
@@ -257,53 +237,39 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
     const float mc = m_i * c;
     float rs = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { snext[0][r] = 0.0f; snext[1][r] = 0.0f; }
-    if (PROF) c1 = stamp();
-    // sched_barrier(0) pins one {MFMA, its VALU shadow work, at most one DMA piece} group after the other: left alone,
-    // hipcc hoists all 8 LDS-DMA pieces into one burst (which blocks the wave) and clusters the MFMAs at the end.
+    for (int r = 0; r < 16; ++r) snext[r] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      snext[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], snext[0], 0, 0, 0);
-      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[0][kk], c, -mc)); scur[0][kk] = pv; rs += pv; }
-      if (kk & 1) glds16(ksrc[kk >> 1], kdst + (kk >> 1) * 1024);   // K(t+2): one DMA piece every second MFMA
+      snext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], snext, 0, 0, 0);
+      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kk], c, -mc)); scur[kk] = pv; rs += pv; }
+      if (kk == 1) glds16(ksrc[0], kdst);            // K(t+2)
+      if (kk == 3) glds16(ksrc[1], kdst + 1024);
+      if (kk == 5) glds16(vsrc[0], vdst);            // V(t+1)
+      if (kk == 7) glds16(vsrc[1], vdst + 1024);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      snext[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], snext[1], 0, 0, 0);
-      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[0][8 + kk], c, -mc)); scur[0][8 + kk] = pv; rs += pv; }
-      if (kk & 1) glds16(vsrc[kk >> 1], vdst + (kk >> 1) * 1024);   // V(t+1)
-      if (kk == 3) load_v(sv, 2, vf[2]);
-      if (kk == 5) load_v(sv, 3, vf[3]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("" : "+v"(snext[0]), "+v"(snext[1]));
-    if (PROF) c2 = stamp();
-    // Oᵀ += Vᵀ·Pᵀ: groups of 16 keys; groups 0,1 (keys 0..31) overlap the exps of keys 32..63
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const bf16x8 pf = pack8(scur[0], 8 * g);
+    {
+      const bf16x8 pf = pack8(scur, 0);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g][d], pf, o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[d], pf, o[d], 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int r = 8 * g + 2 * d + e;
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[1][r], c, -mc)); scur[1][r] = pv; rs += pv;
+          const int r = 8 + 2 * d + e;
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[r], c, -mc)); scur[r] = pv; rs += pv;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    {
+      const bf16x8 pf = pack8(scur, 8);
 #pragma unroll
-    for (int g = 2; g < 4; ++g) {
-      const bf16x8 pf = pack8(scur[1], 8 * (g - 2));
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g][d], pf, o[d], 0, 0, 0);
+      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[d], pf, o[d], 0, 0, 0);
     }
+    asm volatile("" : "+v"(snext));
     rs += __shfl_xor(rs, 32, 64);
     l_i += rs;
-    if (PROF) { c3 = stamp(); pt[4] += c1 - c0; pt[5] += c2 - c1; pt[6] += c3 - c2; }
   };
 
   if (total_tiles > 0) {
@@ -318,17 +284,14 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
     stage_v(0, it0);
     if (total_tiles > 1) stage_k(1, it1);
     __syncthreads();   // vmcnt(0) + barrier
-    f32x16 sa[2], sb[2];
+    f32x16 sa, sb;
     {
-      bf16x8 kf0[8], kf1[8];
-      load_k(kring, 0, kf0);
-      load_k(kring, 1, kf1);
+      bf16x8 kf[8];
+      load_k(kring, kf);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[0][r] = 0.0f; sa[1][r] = 0.0f; }
+      for (int r = 0; r < 16; ++r) sa[r] = 0.0f;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) sa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], sa[0], 0, 0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) sa[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], sa[1], 0, 0, 0);
+      for (int kk = 0; kk < 8; ++kk) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sa, 0, 0, 0);
     }
     TileIt it_cur = it0, it_nxt = it1, it_nn = advance(it1);
     // tile t is in `sa`; Sᵀ of tile t+1 is produced into `sb` and moved over at the end of the step
@@ -338,27 +301,51 @@ __global__ void __launch_bounds__(256, 1) attn_kernel(const AttnArgs p) {
       if (PROF) t0 = stamp();
       __syncthreads();   // K(t+1), V(t) landed; every wave finished QK(t) and PV(t-1)
       if (PROF) t1 = stamp();
-      // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the iterators stay on the last
-      // tile: the redundant pieces land in slots nobody reads again (and are drained before the epilogue).
-      const char* ksrc[4]; const char* vsrc[4];
+      // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the cursors stay on the last
+      // tile: the redundant pieces land in slots nobody reads again (and are drained before the merge).
+      const char* ksrc[2]; const char* vsrc[2];
       k_src(it_nn, ksrc);
       v_src(it_nxt, vsrc);
-      char* kdst = kring + (t & 1) * K_TILE_BYTES + wid * 4096;
-      char* vdst = vring + ((t + 1) & 1) * V_TILE_BYTES + wid * 4096;
+      char* kdst = kring + (t & 1) * K_TILE_BYTES + wid * 2048;
+      char* vdst = vring + ((t + 1) & 1) * V_TILE_BYTES + wid * 2048;
       if (tile_needs_mask(it_cur)) apply_mask(sa, it_cur);
       if (PROF) t2 = stamp();
       compute(sa, sb, kring + ((t + 1) & 1) * K_TILE_BYTES, vring + (t & 1) * V_TILE_BYTES, ksrc, kdst, vsrc, vdst);
       if (PROF) { const unsigned long long t3 = stamp(); pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += 1; }
-      sa[0] = sb[0]; sa[1] = sb[1];
+      sa = sb;
       it_cur = it_nxt; it_nxt = it_nn; it_nn = advance(it_nn);
     }
   }
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the rings are reused / the workgroup ends
   if (PROF && lane == 0) {
-    unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
-    dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4]; dst[5] = pt[5]; dst[6] = pt[6];
+    unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wid) * 8;
+    dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3];
   }
+
+  // ---- merge the two key halves of each query block: waves kh = 1 park (O, m, l) in LDS, waves kh = 0 combine
+  __syncthreads();
+  float* mo = (float*)smem + qb * (64 * 66);      // per query block: 64 lanes x (64 O values + m + l), lane-major stride 66
+  if (kh == 1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mo[(d * 16 + r) * 64 + lane] = o[d][r];
+    mo[64 * 64 + lane] = m_i;
+    mo[65 * 64 + lane] = l_i;
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  {
+    const float m_b = mo[64 * 64 + lane], l_b = mo[65 * 64 + lane];
+    const float m = fmaxf(m_i, m_b);
+    const float fa = __builtin_amdgcn_exp2f((m_i - m) * c), fb = __builtin_amdgcn_exp2f((m_b - m) * c);
+    l_i = l_i * fa + l_b * fb;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * fa + mo[(d * 16 + r) * 64 + lane] * fb;
+  }
+
   // ---- epilogue: lane holds O[q][32d + 8g + 4fh + 0..3]
   if (!q_ok) return;
   const float inv_l = 1.0f / l_i;
@@ -403,10 +390,10 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.S + QT - 1) / QT, a.H, a.rows);
   bool bias = false;
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
-  if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(256), SMEM, st, a);   // s_memtime stamps
-  else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(256), SMEM, st, a);
-  else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(256), SMEM, st, a);
-  else if (bias) hipLaunchKernelGGL((attn_kernel<false, true, false>), grid, dim3(256), SMEM, st, a);
-  else hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(256), SMEM, st, a);
+  if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(512), SMEM, st, a);   // s_memtime stamps
+  else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(512), SMEM, st, a);
+  else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(512), SMEM, st, a);
+  else if (bias) hipLaunchKernelGGL((attn_kernel<false, true, false>), grid, dim3(512), SMEM, st, a);
+  else hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(512), SMEM, st, a);
   return hipGetLastError();
 }

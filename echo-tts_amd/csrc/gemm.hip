@@ -23,6 +23,9 @@ void gemm_args_init(GemmArgs* g) {
 namespace {
 
 constexpr int KBYTES = 128;   // K step: 128 bytes per row (64 bf16 / 32 fp32)
+#ifndef DMA_SPREAD_DEN
+#define DMA_SPREAD_DEN 2
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
     // spread over the tile instead of being hoisted into one burst
     auto after_mfma = [&]() {
       ++mf;
-      if (piece < PPW && mf * PPW >= (piece + 1) * NMF) {
+      if (piece < PPW && mf * PPW * DMA_SPREAD_DEN >= (piece + 1) * NMF) {   // all pieces go out in the first 1/DMA_SPREAD_DEN of the tile
         if (more) glds16(nsrc[piece], ndst + piece * 1024);
         ++piece;
         __builtin_amdgcn_sched_barrier(0);

@@ -44,7 +44,7 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     fl = 4.0 * S * keys * D
     print(f"attn R={R} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
     nwg = ((S + 127) // 128) * H * R
-    prof = torch.zeros((nwg * 4, 8), dtype=torch.int64, device=dev)
+    prof = torch.zeros((nwg * 8, 8), dtype=torch.int64, device=dev)
     d.prof = prof.data_ptr()
     L.check(lib.echo_op_attention_bf16(C.byref(d), U.stream()))
     torch.cuda.synchronize()
@@ -52,7 +52,6 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     tiles = pr[:, 3].clamp_min(1)
     print("   per-tile cycles (mean over waves): barrier %.0f  issue+mask %.0f  compute %.0f   | tiles/wave mean %.1f max %.0f" %
           ((pr[:, 0] / tiles).mean(), (pr[:, 1] / tiles).mean(), (pr[:, 2] / tiles).mean(), tiles.mean(), tiles.max()))
-    print("   inside compute: loads+max+rescale %.0f  QK+exp+dma %.0f  PV %.0f" % tuple((pr[:, i] / tiles).mean() for i in (4, 5, 6)))
     big = pr[pr[:, 3] == pr[:, 3].max()]
     print("   longest waves: barrier %.0f issue %.0f compute %.0f (cycles per tile)" % tuple((big[:, i] / big[:, 3]).mean() for i in range(3)))
 
