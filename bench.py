@@ -137,18 +137,27 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
+    ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
     args = ap.parse_args()
 
     from echo_tts_amd import parallel as P
-    rank, world, local = P.init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.force_device is not None:
+        os.environ["ECHO_FORCE_DEVICE"] = str(args.force_device)
+    rank, world, local = P.init_distributed(backend=args.dist_backend)
+    if args.force_device is not None:
+        local = args.force_device
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     E, model, dac, pca, ids, tmask, spk, smask = build(device, rank, world)
 
+    last = {}
+
     def utterance(seed: int):
         lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=seed, **SAMPLER)
+        last["latent"] = lat
         return E.ae_decode(dac, pca, lat)
 
     for i in range(args.warmup):
@@ -169,7 +178,9 @@ def main() -> None:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert bool(torch.isfinite(wav).all()), "non-finite waveform"
+    if not bool(torch.isfinite(wav).all()):
+        raise SystemExit(f"rank {rank}: non-finite waveform (latent finite: {bool(torch.isfinite(last['latent']).all())}, "
+                         f"latent rms {float(last['latent'].float().pow(2).mean().sqrt()):.3g})")
 
     roofline = None
     phases = None

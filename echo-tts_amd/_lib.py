@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libechohip.so")
+LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
 ABI_VERSION = 1

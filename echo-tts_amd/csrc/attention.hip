@@ -267,7 +267,6 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[d], pf, o[d], 0, 0, 0);
     }
-    asm volatile("" : "+v"(snext));
     rs += __shfl_xor(rs, 32, 64);
     l_i += rs;
   };
@@ -299,6 +298,10 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     for (int t = 0; t < total_tiles; ++t) {
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
       if (PROF) t0 = stamp();
+      // Every wave's DMA pieces of K(t+1) / V(t) must have landed before anyone reads them.  hipcc does NOT put the
+      // vmcnt wait into __syncthreads() here (it only tracked the prologue's DMAs): without this explicit wait the
+      // kernel was non-deterministic at full size (caught by tests/test_gpu_kernels.py::test_attention_is_deterministic).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // K(t+1), V(t) landed; every wave finished QK(t) and PV(t-1)
       if (PROF) t1 = stamp();
       // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the cursors stay on the last

@@ -225,6 +225,16 @@ struct Engine : EngineBase {
     if (it == plans.end()) {
       Plan best;
       const int nk = g.K / KEu * g.taps;
+      if (const char* f = getenv("ECHO_GEMM_FORCE")) {   // "cfg,ksplit": debugging aid, applied wherever legal
+        int fc = 0, fk = 1;
+        if (sscanf(f, "%d,%d", &fc, &fk) == 2 && fc >= 0 && fc < gemm_num_cfgs()) {
+          best.cfg = fc;
+          if (fk > 1 && g.nbatch == 1 && !g.qkv_mode && nk / fk >= 1) best.ksplit = fk;
+          plans.emplace(key, best);
+          it = plans.find(key);
+        }
+      }
+      if (it == plans.end()) {
       const long t128 = (long)((g.M + 127) / 128) * (g.Npad / 128);
       if (tune_enabled && (long)g.M * g.N * g.K * g.taps >= (1L << 28)) {
         // time every candidate on the real operands with a scratch output (the tail is irrelevant for the ranking)
@@ -270,6 +280,7 @@ struct Engine : EngineBase {
                   g.swiglu, (int)sizeof(U), best.cfg, best.ksplit, best_ms * 1e3f / 3);
       }
       it = plans.emplace(key, best).first;
+      }
     }
     g.cfg = it->second.cfg;
     g.ksplit = it->second.ksplit;

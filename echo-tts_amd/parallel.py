@@ -27,7 +27,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("ECHO_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -61,7 +61,7 @@ def broadcast_state(spec: Sequence[Tuple[str, Tuple[int, ...]]], state: Optional
             for name, shape, n in bucket:
                 flat[off:off + n] = state[name].to(device=device, dtype=dtype).reshape(-1)
                 off += n
-        dist.broadcast(flat, src=src)
+        dist.broadcast(flat.view(torch.uint8), src=src)   # raw bytes: independent of the backend's dtype support
         off = 0
         for name, shape, n in bucket:
             out[name] = flat[off:off + n].view(shape)

@@ -336,3 +336,48 @@ def test_gemm_f32_split3_accuracy(cfg):
     ref = A.double() @ W[:N].double().T
     rel = ((out.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     assert rel < 3e-5, rel
+
+
+@pytest.mark.parametrize("R", [3, 1])
+def test_attention_is_deterministic_at_full_size(R):
+    """Same launch three times at the C2 shape (S=640, 16 heads, 436 text + 640 speaker keys): bit-identical and finite.
+    Guards the LDS-DMA ring synchronisation (a missing vmcnt wait before the tile barrier showed up only at this size)."""
+    S, H, Lt, Ls = 640, 16, 436, 640
+    D = H * 128
+    qkvg = rnd(R * S + 256, 4 * D, dtype=torch.bfloat16, scale=0.5)
+    pS, pT, pSp = (S + 63) // 64 * 64, (Lt + 63) // 64 * 64, (Ls + 63) // 64 * 64
+    vt_self = rnd(R, H, 128, pS, dtype=torch.bfloat16, seed=1)
+    kt, vt_t = rnd(Lt + 128, 4 * D, dtype=torch.bfloat16, seed=2), rnd(1, H, 128, pT, dtype=torch.bfloat16, seed=3)
+    ksp, vt_s = rnd(Ls + 128, 4 * D, dtype=torch.bfloat16, seed=4), rnd(1, H, 128, pSp, dtype=torch.bfloat16, seed=5)
+    rows = [[S] * R, [Lt, 0, Lt][:R], [Ls, Ls, 0][:R]]
+    nk = torch.tensor(rows, dtype=torch.int32, device=DEV)
+    outs = []
+    for _ in range(3):
+        out = torch.zeros((R * S, D), dtype=torch.bfloat16, device=DEV)
+        d = L.EchoAttnDesc()
+        d.Q, d.q_ld, d.q_row_stride = qkvg.data_ptr(), 4 * D, S * 4 * D
+        d.O, d.o_ld, d.o_row_stride = out.data_ptr(), D, S * D
+        d.G, d.g_ld, d.g_row_stride = qkvg.data_ptr() + 3 * D * 2, 4 * D, S * 4 * D
+        d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 3, 0, 1 / math.sqrt(128)
+        for i, (kp, kld, krs, vt, pitch, shared) in enumerate(((qkvg.data_ptr() + D * 2, 4 * D, S * 4 * D, vt_self, pS, False),
+                                                               (kt.data_ptr(), 4 * D, 0, vt_t, pT, True),
+                                                               (ksp.data_ptr(), 4 * D, 0, vt_s, pSp, True))):
+            sg = d.seg[i]
+            sg.K, sg.k_ld, sg.k_head_stride, sg.k_row_stride = kp, kld, 128, krs
+            sg.Vt, sg.vt_ld, sg.vt_head_stride = vt.data_ptr(), pitch, 128 * pitch
+            sg.vt_row_stride = 0 if shared else H * 128 * pitch
+            sg.nkeys = nk[i].data_ptr()
+            sg.kv_mod = 1 if shared else 0
+        L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert bool(torch.isfinite(outs[0].float()).all())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # and it is right: fp32 reference of row 0, head 0
+    q = qkvg[:S, :128].float()
+    k = torch.cat([qkvg[:S, D:D + 128], kt[:Lt, :128], ksp[:Ls, :128]]).float()
+    v = torch.cat([vt_self[0, 0, :, :S].T, vt_t[0, 0, :, :Lt].T, vt_s[0, 0, :, :Ls].T]).float()
+    ref = torch.softmax(q @ k.T / math.sqrt(128), -1) @ v
+    ref = (ref.bfloat16().float() * torch.sigmoid(qkvg[:S, 3 * D:3 * D + 128].float()).bfloat16().float())
+    err = (outs[0][:S, :128].float() - ref).abs()
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3

@@ -29,6 +29,10 @@ def _worker(rank: int, world: int, port: int, q) -> None:
     g = torch.Generator().manual_seed(0)
     want = {n: torch.randn(s, generator=g) for n, s in spec}
     ok = all(torch.equal(got[n], want[n]) for n, _ in spec)
+    # bf16 checkpoints travel as raw bytes
+    st16 = {n: want[n].bfloat16() for n, _ in spec} if r == 0 else None
+    got16 = P.broadcast_state(spec, st16, "cpu", torch.bfloat16, bucket_bytes=1 << 20)
+    ok = ok and all(torch.equal(got16[n], want[n].bfloat16()) for n, _ in spec)
     res = P.run_data_parallel(5, lambda i: torch.full((i + 1,), float(i)))
     if r == 0:
         ok = ok and [t.tolist() for t in res] == [[float(i)] * (i + 1) for i in range(5)]
