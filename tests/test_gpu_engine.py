@@ -176,3 +176,86 @@ def test_dac_is_causal_and_length_independent(golden):
     a = dac.decode_zq(z[..., :24])
     b = dac.decode_zq(z)
     assert rms(a, b[..., : a.shape[-1]]) < 1e-6
+
+
+def test_c1_full_depth_fp32_against_oracle():
+    """BASELINE config C1 at FULL size (24-layer EchoDiT, 14-layer encoders): '[S1] Hello world.' (18 tokens), no speaker
+    reference, S=128, 10 Euler steps, CFG off.  The fp32 engine must match the CPU oracle (fp32, same seeded weights)
+    within the north-star latent tolerance."""
+    from echo_tts_amd.inference import get_text_input_ids_and_mask
+    cfg = R.DiTConfig()
+    w = R.make_dit_weights(cfg, seed=0, with_blockwise=False)
+    ids, tmask = get_text_input_ids_and_mask(["[S1] Hello world."], max_length=None)
+    assert ids.shape == (1, 18)
+    spk = torch.zeros((1, 4, 80))
+    smask = torch.zeros((1, 4), dtype=torch.bool)
+    x0 = torch.randn((1, 128, 80), generator=torch.Generator().manual_seed(0))
+    assert abs(float(x0[0, 0, 0]) + 1.12584) < 1e-4       # SURVEY.md §8c: first value of the CPU generator, seed 0
+    kw = dict(num_steps=10, cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_min_t=1.1, cfg_max_t=1.0, truncation_factor=None,
+              rescale_k=None, rescale_sigma=None, speaker_kv_scale=None, speaker_kv_max_layers=None, speaker_kv_min_t=None)
+    torch.set_num_threads(16)
+    want = R.sample_euler(w, cfg, torch.float32, spk, smask, ids, tmask, rng_seed=0, sequence_length=128, x_init=x0, **kw)
+    m = E.EchoDiT(cfg, w, dtype=torch.float32, device=DEV)
+    got = E.sample_euler_cfg_independent_guidances(m, spk, smask, ids, tmask, rng_seed=0, sequence_length=128, x_init=x0, **kw)
+    e = rms(got, want)
+    assert e < LAT_TOL, (e, U.rms(want))
+    del m
+    mb = E.EchoDiT(cfg, {k: v.bfloat16() for k, v in w.items()}, dtype=torch.bfloat16, device=DEV)
+    gotb = E.sample_euler_cfg_independent_guidances(mb, spk, smask, ids, tmask, rng_seed=0, sequence_length=128, x_init=x0, **kw)
+    eb = rms(gotb, want)
+    # calibration: PyTorch's own bf16 run (the oracle in bf16 on the CPU) against its fp32 run, same weights
+    wantb = R.sample_euler({k: v.bfloat16() for k, v in w.items()}, cfg, torch.bfloat16, spk, smask, ids, tmask, rng_seed=0,
+                           sequence_length=128, x_init=x0, **kw)
+    eref = rms(wantb, want)
+    print(f"C1 full depth: fp32 engine rms {e:.3e}; bf16 engine rms {eb:.3e} vs fp32 oracle; PyTorch bf16 vs fp32 {eref:.3e}; "
+          f"bf16 engine vs PyTorch bf16 {rms(gotb, wantb):.3e} (latent rms {U.rms(want):.3f})")
+    assert eb < 1.5 * eref + 1e-3, (eb, eref)
+
+
+@pytest.mark.parametrize("dname,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_pipeline_and_handler_surface(golden, tiny_models, dname, dt):
+    """sample_pipeline / sample_pipeline_chunked / handler.synthesize run end to end on the tiny models (text front end,
+    sampler, ae_decode, crop, chunking, cross-fade) and agree with the oracle evaluated stage by stage."""
+    from functools import partial
+    from echo_tts_amd import handler as H
+    from echo_tts_amd import inference as inf
+    m = tiny_models[dname]
+    dw = R.make_dac_weights(TINY_DAC, 0)
+    dac = E.DAC(TINY_DAC, dw, device=DEV)
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    fn = partial(E.sample_euler_cfg_independent_guidances, sequence_length=32, **SAMPLER_CASES["cfg_default"])
+    g = golden
+    audio, norm = E.sample_pipeline(m, dac, st, fn, "Hello world.", None, 3, pad_to_max_text_length=64,
+                                    speaker_latent=g["tiny.spk"], speaker_mask=g["tiny.smask"].bool())
+    assert norm == "[S1] Hello world." and audio.shape[:2] == (1, 1) and audio.shape[-1] % 2048 == 0
+    assert bool(torch.isfinite(audio).all())
+    if dt == torch.float32:
+        # the same request through the oracle: text ids, sampler (with the device's own noise), decode, crop
+        ids, tmask = inf.get_text_input_ids_and_mask(["Hello world."], max_length=64)
+        x0 = torch.randn((1, 32, 80), device=DEV, dtype=torch.float32, generator=torch.Generator(device=DEV).manual_seed(3)).cpu()
+        w = R.make_dit_weights(TINY, seed=0)
+        lat = R.sample_euler(w, TINY, torch.float32, g["tiny.spk"], g["tiny.smask"].bool(), ids, tmask, rng_seed=3,
+                             sequence_length=32, x_init=x0, **SAMPLER_CASES["cfg_default"])
+        wav = R.ae_decode(dw, TINY_DAC, pca, lat)
+        wav = wav[..., : R.find_flattening_point(lat[0]) * 2048]
+        assert wav.shape == audio.shape
+        assert rms(audio, wav) < WAV_TOL
+    long_text = "First sentence here. Second sentence follows, with a clause. Third one!"
+    a2, n2 = E.sample_pipeline_chunked(m, dac, st, fn, long_text, None, 0, max_chars_per_chunk=30, pad_to_max_text_length=64)
+    assert n2.count("\n") == len(inf.chunk_text(long_text, 30)) - 1 and bool(torch.isfinite(a2).all())
+    out = H.synthesize({"text": long_text, "parameters": {"num_steps": 4, "sequence_length": 32, "target_duration_seconds": 2.5}},
+                       m, dac, st)
+    assert "error" not in out, out.get("traceback")
+    assert out["chunks"] == len(H.chunk_text_for_audio(long_text, 300, 2.5)) and out["audio"].shape[-1] > 0
+
+
+@pytest.mark.parametrize("case,opts,cont", [("plain", "cfg_default", False), ("cont_opts", "all_options", True)])
+def test_blockwise_sampler_bf16_within_reference_noise(golden, tiny_models, case, opts, cont):
+    g, m = golden, tiny_models["bf16"]
+    xi = [g[f"tiny.blk_x{j}"] for j in range(3)]
+    lat = E.sample_blockwise_euler_cfg_independent_guidances(
+        m, g["tiny.spk"], g["tiny.smask"].bool(), g["tiny.ids"], g["tiny.tmask"].bool(), rng_seed=0, block_sizes=[16, 8, 8],
+        continuation_latent=g["tiny.blk_cont"] if cont else None, x_inits=xi, **SAMPLER_CASES[opts])
+    e = rms(lat, g[f"tiny.f32.blockwise.{case}"])
+    assert e < _bf16_budget(g, f"tiny.bf16.blockwise.{case}", f"tiny.f32.blockwise.{case}"), e
