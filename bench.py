@@ -43,17 +43,17 @@ AUDIO_S = S * 2048 / 44100.0
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def dit_gemm_flops() -> float:
+def dit_gemm_flops(batch: int = 1) -> float:
     """Algorithmic FLOPs of the gemm_nt launches inside one sampler run: 80 row-forwards of
     S * 2 743 730 176 plus the one-time modulation tables (cond MLP + 144 low-rank refinements for 40 timesteps)."""
     D, F, Lz, L, R, E = 2048, 5888, 80, 24, 256, 512
     per_row = S * (2 * L * (5 * D * D + 3 * D * F) + 2 * 2 * Lz * D)
     rows = 20 * 3 + 20
     mod = 2 * STEPS * (E * D + D * D + D * 3 * D) + 2 * STEPS * (2 * L * 3) * (2 * D * R)
-    return float(rows * per_row + mod)
+    return float(batch * rows * per_row + mod)
 
 
-def build(device, rank: int, world: int, concurrency: int = 1):
+def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1):
     import echo_tts_amd as E
     from echo_tts_amd import parallel as P
     from echo_tts_amd.weights import dac_param_shapes, dit_param_shapes, random_dac_state, random_dit_state
@@ -78,6 +78,10 @@ def build(device, rank: int, world: int, concurrency: int = 1):
     tmask[0, :TVALID] = True
     spk = torch.randn((1, TS, cfg.latent_size), generator=g).to(device)
     smask = torch.ones((1, TS), dtype=torch.bool)
+    if batch > 1:
+        # the reference's own batch axis (inference.py:448-449): `batch` utterances through one sampler call, each with its
+        # own noise; every row carries its own text / speaker KV like any (B, ...) call of the reference
+        ids, tmask, spk, smask = ids.repeat(batch, 1), tmask.repeat(batch, 1), spk.repeat(batch, 1, 1), smask.repeat(batch, 1)
     return E, models, dacs, pca, ids.to(device), tmask, spk, smask
 
 
@@ -145,6 +149,8 @@ def main() -> None:
     ap.add_argument("--concurrency", type=int, default=2,
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
     args = ap.parse_args()
@@ -160,7 +166,8 @@ def main() -> None:
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     conc = max(1, args.concurrency)
-    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc)
+    nb = max(1, args.batch)
+    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc, nb)
     model, dac = models[0], dacs[0]
     streams = [torch.cuda.Stream(device=device) for _ in range(conc)] if conc > 1 else [torch.cuda.current_stream(device)]
 
@@ -206,7 +213,7 @@ def main() -> None:
         lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=7, **SAMPLER)
         pr = model.get_profile()
         model.set_profiling(False)
-        flops = dit_gemm_flops()
+        flops = dit_gemm_flops(nb)
         ach = flops / (pr.ms_gemm_sum * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt<bf16> (EchoDiT linears)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -223,14 +230,14 @@ def main() -> None:
         cpu = cpu_baseline(host_threads())
 
     if rank == 0:
-        total_audio = AUDIO_S * args.steps * world * conc
+        total_audio = AUDIO_S * args.steps * world * conc * nb
         out = {
             "metric": "audio-sec/sec/GPU @ seq_len=640, 40 steps, CFG(text=3, spk=8); 1/2/4/8 GPU",
             "value": round(total_audio / dt, 3), "unit": "audio-s/s (whole job; divide by n_gpus for per-GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "per_gpu": round(total_audio / dt / world, 3),
-            "config": {"workload": f"C2: {conc} independent utterance(s)/step/GPU on {conc} HIP stream(s), seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
+            "config": {"workload": f"C2: {conc * nb} utterance(s)/step/GPU ({nb} per sampler call, {conc} HIP stream(s)), seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
                                    "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
                                    "EchoDiT bf16 + Fish S1-DAC decode fp32, random weights",
                        "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},

@@ -14,6 +14,7 @@
 // columns) so that each lane ends up with 4 consecutive output columns of one output row: the
 // epilogue stores 8 B (bf16) / 16 B (fp32) vectors and the SwiGLU pair (w1, w3) lives in one lane.
 #include "common.h"
+#include <cstdlib>
 
 void gemm_args_init(GemmArgs* g) {
   memset(g, 0, sizeof(*g));
@@ -115,6 +116,137 @@ __device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, co
     o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
   }
   *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + j0) = Vec4<T>::pack(o);
+}
+
+// ---- epilogue shared by the tile kernels, 32 output rows per pass through LDS (the staging buffers are free after
+// the last barrier): the owning waves write their accumulators as 16-byte chunks into a [32][BN/4] fp32 slab
+// (chunk ^= row, conflict spreading; `put(pass, slab)`), then all threads re-read it row-wise so that consecutive lanes
+// cover consecutive columns of one row: global stores are whole row segments and the fused tail is emitted once.
+// cycle accounting of the diagnostic build (s_memtime sums per wave; compiled out unless PROF)
+struct EpiProf { unsigned long long t_bar1 = 0, t_put = 0, t_bar2 = 0, t_rw = 0; };
+#define EPI_STAMP(var) do { if constexpr (PROF) { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); prof->var += n__ - last__; last__ = n__; } } while (0)
+
+template <typename T, bool SWIGLU, int BM, int BN, int NT, bool DRAIN, bool PROF = false, typename PutFn>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, int tid, int tile_m, int tile_n, int tiles_m, int zo, int zi,
+                                              long c_z, int split, PutFn put, EpiProf* prof = nullptr) {
+  unsigned long long last__ = 0;
+  if constexpr (PROF) last__ = __builtin_amdgcn_s_memtime();
+  T* C = (T*)p.C + c_z;
+  T* C2 = (T*)p.C2 + c_z;
+  constexpr int CPR = BN / 4;               // chunks per slab row
+  constexpr int NPASS = BM / 32;
+  // DRAIN: the slab reuses the staging buffers, so every LDS-DMA of the main loop must have landed first
+  if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // raw barriers + lgkmcnt only: __syncthreads() would also wait (vmcnt) for the previous pass's global stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    EPI_STAMP(t_bar1);
+    put(pass, slab);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    EPI_STAMP(t_put);
+    __builtin_amdgcn_s_barrier();
+    EPI_STAMP(t_bar2);
+    const int mrow0 = tile_m * BM + pass * 32;
+    if (p.ksplit > 1) {
+      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
+      float* ws = (float*)p.ws + ((long)split * tiles_m * BM + mrow0) * (long)p.Npad + (long)tile_n * BN;
+#pragma unroll
+      for (int idx = tid; idx < 32 * CPR; idx += NT) {
+        const int ml = idx / CPR, chunk = idx % CPR;
+        if (tile_n * BN + chunk * 4 < p.Npad)
+          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+      }
+    } else if constexpr (SWIGLU) {
+      // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
+#pragma unroll
+      for (int idx = tid; idx < 32 * (CPR / 2); idx += NT) {
+        const int ml = idx / (CPR / 2), pc = idx % (CPR / 2);
+        const int b = pc >> 2, q = pc & 3;
+        const int m = mrow0 + ml;
+        const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
+        if (m >= p.M || j0 >= (p.N >> 1)) continue;
+        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + q) ^ ml)) * 4);
+        const f32x4 b4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + 4 + q) ^ ml)) * 4);
+        swiglu_tail<T>(p, m, j0, a4, b4, C);
+      }
+    } else if (p.qkv_mode) {
+      const int D = p.qkv_D;
+      const int sec = (tile_n * BN) / D;           // the whole tile lies in one of q | k | v | gate (D % BN == 0)
+      if (sec == 2) {
+        // V section: transposed store, 8 consecutive tokens of one d per thread
+#pragma unroll
+        for (int idx = tid; idx < BN * 4; idx += NT) {
+          const int col = idx % BN, sg = idx / BN;
+          const int m = mrow0 + 8 * sg;
+          if (m >= p.M) continue;
+          float v8[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int rw = 8 * sg + r;
+            v8[r] = Num<T>::rnd(slab[(rw * CPR + ((col >> 2) ^ rw)) * 4 + (col & 3)]);
+          }
+          const int hd = tile_n * BN + col - 2 * D;        // h * 128 + d
+          const int b = m / p.qkv_S, sidx = m - b * p.qkv_S;
+          T* dst = (T*)p.vt + (long)b * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
+          if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
+            *(typename Vec4<T>::raw*)dst = Vec4<T>::pack(v8);
+            *(typename Vec4<T>::raw*)(dst + 4) = Vec4<T>::pack(v8 + 4);
+          } else {
+            for (int r = 0; r < 8 && m + r < p.M; ++r) {
+              const int bb = (m + r) / p.qkv_S, ss = (m + r) - bb * p.qkv_S;
+              ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(v8[r]);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int idx = tid; idx < 32 * CPR; idx += NT) {
+          const int ml = idx / CPR, chunk = idx % CPR;
+          const int m = mrow0 + ml;
+          const int n0 = tile_n * BN + chunk * 4;
+          const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+          float y[4] = {Num<T>::rnd(a4[0]), Num<T>::rnd(a4[1]), Num<T>::rnd(a4[2]), Num<T>::rnd(a4[3])};
+          if (sec < 2) {
+            // 32 consecutive lanes hold the 128 columns of one (token, head): half-wave reduction of the squares
+            float ss = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float rs = rsqrtf(ss / 128.0f + p.qk_eps);
+            const int nd = n0 - sec * D;                   // h * 128 + d
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[i] = Num<T>::rnd(__fmul_rn(__fmul_rn(y[i], rs), vec_at<T>(p.qk_w, (long)sec * D + nd + i)));
+            if ((nd >> 7) < p.rope_heads) {
+              const int pos = p.pos0 + m % p.qkv_S;
+              const float2* rp = (const float2*)p.rope + (long)pos * 64 + ((nd & 127) >> 1);
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                const float2 cs = rp[pr];
+                const float a = y[2 * pr], bq = y[2 * pr + 1];
+                y[2 * pr] = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(bq, cs.y));
+                y[2 * pr + 1] = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(bq, cs.x));
+              }
+            }
+          }
+          if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int idx = tid; idx < 32 * CPR; idx += NT) {
+        const int ml = idx / CPR, chunk = idx % CPR;
+        const int m = mrow0 + ml;
+        const int n0 = tile_n * BN + chunk * 4;
+        if (m >= p.M || n0 >= p.N) continue;
+        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+        float y[4] = {a4[0], a4[1], a4[2], a4[3]};
+        gemm_tail<T>(p, m, n0, y, zo, zi, C, C2);
+      }
+    }
+    EPI_STAMP(t_rw);
+  }
 }
 
 // SPLIT3 (fp32 only): every fp32 operand x is split in registers into bf16 hi = bf16(x), lo = bf16(x - hi) and the
@@ -312,28 +444,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
     }
   }
 
-  // ---- epilogue, 32 output rows per pass through LDS (the staging buffers are free after the last barrier):
-  // the owning waves write their accumulators as 16-byte chunks into a [32][BN/4] fp32 slab (chunk ^= row, conflict
-  // spreading), then all threads re-read it row-wise so that consecutive lanes cover consecutive columns of one row:
-  // global stores are whole row segments and the fused tail is emitted once.
-  T* C = (T*)p.C + c_z;
-  T* C2 = (T*)p.C2 + c_z;
-  float* slab = (float*)smem;
-  constexpr int CPR = BN / 4;               // chunks per slab row
-  constexpr int NPASS = BM / 32;
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-    __builtin_amdgcn_s_waitcnt(0);          // (vmcnt/lgkmcnt drained; expcnt too)
-    __syncthreads();
+  // ---- epilogue (gemm_epilogue): this wave's accumulators of one 32-row pass go into the LDS slab
+  const int fr_ = fr, fh_ = fh;
+  gemm_epilogue<T, SWIGLU, BM, BN, CF::NT, true>(p, (float*)smem, tid, tile_m, tile_n, tiles_m, zo, zi, c_z, split, [&](int pass, float* slab) {
+    constexpr int CPR = BN / 4;
     if (wm == pass / TM) {
       const int tm_sel = pass % TM;
       auto put = [&](const f32x16& a, int tn) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int chunk = wn * (CF::WN / 4) + tn * 8 + 2 * g + fh;
+          const int chunk = wn * (CF::WN / 4) + tn * 8 + 2 * g + fh_;
           f32x4 v;
           v[0] = a[4 * g]; v[1] = a[4 * g + 1]; v[2] = a[4 * g + 2]; v[3] = a[4 * g + 3];
-          *(f32x4*)(slab + (fr * CPR + (chunk ^ fr)) * 4) = v;
+          *(f32x4*)(slab + (fr_ * CPR + (chunk ^ fr_)) * 4) = v;
         }
       };
 #pragma unroll
@@ -345,105 +468,476 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
         if constexpr (TM > 3) { if (tm_sel == 3) put(acc[tn][3], tn); }
       }
     }
-    __syncthreads();
-    const int mrow0 = tile_m * BM + pass * 32;
-    if (p.ksplit > 1) {
-      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
-      float* ws = (float*)p.ws + ((long)split * tiles_m * BM + mrow0) * (long)p.Npad + (long)tile_n * BN;
-#pragma unroll 1
-      for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
-        const int ml = idx / CPR, chunk = idx % CPR;
-        if (tile_n * BN + chunk * 4 < p.Npad)
-          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_pp_kernel: bf16, 256x256 output tile, K-tile 64, 8 waves (4 M x 2 N, 64 x 128 outputs each) on
+// v_mfma_f32_16x16x32_bf16, written for one workgroup per CU (160 KiB LDS, <= 256 VGPRs).
+//
+// The two waves of every SIMD (wave w and w + 4) run the same program HALF A PHASE APART ("ping-pong"): while one is
+// inside a cluster of 16 MFMAs, its partner issues the LDS fragment reads and the LDS-DMA of its next phase, and they
+// swap roles at every workgroup barrier, so the matrix pipe of the SIMD always has one wave feeding it
+// (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md §5 "256² 8-phase").
+//
+// A K-tile is 4 phases; phase q computes one 32 x 64 quadrant of the wave's outputs over K = 64:
+//     q0 (m-half 0, n-half 0)   q1 (0, 1)   q2 (1, 1)   q3 (1, 0)
+// and reads only the fragments it does not hold yet: q0 A(m-half 0) + W(n-half 0), q1 W(n-half 1), q2 A(m-half 1).
+// The LDS image of a K-tile is cut the same way into four 16 KiB UNITS, staged one per phase in the order they are
+// first read:  j0 = A rows of m-half 0 (all four wave rows),  j1 = W rows of n-half 0 (both wave columns),
+// j2 = W n-half 1,  j3 = A m-half 1.  Unit u = 4t + j is issued in phase u - LEAD (2 LDS-DMA instructions per wave)
+// into a ring of two K-tiles.  Ordering, with G0 = waves 0-3 and G1 = waves 4-7 one barrier behind:
+//   RAW  every wave waits for its own DMA of the units first read in phase r with a counted vmcnt in the load part of
+//        phase r - 1 (at most 2 (LEAD - 2) younger DMAs stay in flight), then passes the barrier that ends that
+//        part; both groups have done so before either reads (G0 reads two barriers, G1 one barrier later);
+//   WAR  unit u overwrites unit u - 8, last read in phase u - 8 - {0,1,1,1}[j]; those reads are retired by the
+//        lgkmcnt(0) at the head of that phase's MFMA part, so restaging two phases later is safe: LEAD <= 6.
+// Never vmcnt(0) in the loop: the look-ahead units of the last phases re-stage the final K-tile into dead ring slots.
+//
+// The kernel is PERSISTENT: gridDim.x workgroups (one per CU) walk the tile list with stride gridDim.x, and the unit
+// stream simply continues from the last K-tile of one output tile into the first K-tile of the next, so the LDS-DMA of
+// the next tile is in flight while the accumulators of the current one go through the epilogue.
+//
+// Epilogue (pp_epilogue): no workgroup barriers.  Tails that work per output column or per (row, head) run on the
+// accumulator layout in registers (SwiGLU pairs, q/k head RMSNorm + RoPE: a wave owns 128 columns = one head); then
+// every wave turns its own 16-row x 64-column pieces through a PRIVATE 4 KiB LDS area (behind the ring) into rows of
+// 8 consecutive columns per lane, applies the row-layout tail (bias / activation / column scale / residual / Snake) and
+// stores 16 bytes per lane: each store instruction writes eight whole 128-byte lines.  The V section of the fused QKV
+// projection takes the same route with rows and columns exchanged (Vᵀ is written 8 tokens per lane).
+#ifndef PP_LEAD
+#define PP_LEAD 5
+#endif
+#ifndef PP_GN
+#define PP_GN 4
+#endif
+template <int V> struct IC { static constexpr int value = V; };
+
+__device__ __forceinline__ uint4 pack8_bf16(const float* y) {
+  uint4 r;
+  r.x = pack_bf16x2(y[0], y[1]); r.y = pack_bf16x2(y[2], y[3]); r.z = pack_bf16x2(y[4], y[5]); r.w = pack_bf16x2(y[6], y[7]);
+  return r;
+}
+__device__ __forceinline__ void unpack8_bf16(uint4 r, float* f) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// gemm_tail on 8 consecutive bf16 columns (same operation order and rounding points); GELU / Snake / the second output
+// belong to the fp32 DAC path and are rejected at launch for this kernel
+__device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, float (&y)[8], int zo, int zi, bf16_t* C) {
+  typedef bf16_t T;
+  if (p.acc_scale != 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] *= p.acc_scale;
+  }
+  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
+  if (p.bias) {
+    float b[8];
+    unpack8_bf16(*(const uint4*)((const T*)p.bias + zo * p.bias_bo + zi * p.bias_bi + nv), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] += b[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i]);
+  if (p.div != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
+  }
+  if (p.colscale) {
+    float c[8];
+    unpack8_bf16(*(const uint4*)((const T*)p.colscale + nv), c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] * c[i]);
+  }
+  if (p.res) {
+    float r[8];
+    unpack8_bf16(*(const uint4*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
+  }
+  *(uint4*)(C + (long)m * p.ldc + n0) = pack8_bf16(y);
+}
+
+// DIAG (timing experiments only): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 4 = no epilogue
+// (1-4 give wrong results); 5 = correct results + per-wave cycle sums (s_memtime) written to p.ws: {total, K loops,
+// epilogue, tiles} x 8 waves per workgroup
+template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD>
+__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, KE = 64, UNIT = 16384, KTILE = 4 * UNIT;
+  static_assert(LEAD >= 2 && LEAD <= 6, "see the WAR/RAW rules above");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Npad + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;                       // <= ntiles
+  // virtual block id v -> tile: bijective XCD remap (workgroups that share an XCD walk one contiguous run of tiles;
+  // G is a multiple of 8 or equals ntiles, so v % 8 == blockIdx.x % 8 for every tile of this workgroup)
+  // The linear index b runs through strips of PP_GN tile columns, row by row inside a strip: the 32 tiles an XCD works
+  // on at one time form an 8 x 4 block (8 A panels + 4 W panels through its L2 instead of 32 + 1).
+  auto tile_of = [&](int v, int& tm, int& tn) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GN = PP_GN;
+    const int strip = b / (GN * tiles_m), rem = b - strip * (GN * tiles_m);
+    const int w = tiles_n - strip * GN < GN ? tiles_n - strip * GN : GN;
+    tm = rem / w; tn = strip * GN + (rem - tm * w);
+  };
+  const int z = blockIdx.y, zo = z / p.nbi, zi = z - zo * p.nbi;
+  const long a_z = zo * p.a_bo + zi * p.a_bi, w_z = zo * p.w_bo + zi * p.w_bi, c_z = zo * p.c_bo + zi * p.c_bi;
+
+  const int kb_per_tap = p.K / KE;
+  const int nk_total = kb_per_tap * p.taps;
+  const int ks = p.ksplit > 1 ? p.ksplit : 1;
+  const int split = blockIdx.z;
+  const int it0 = (int)((long)nk_total * split / ks), it1 = (int)((long)nk_total * (split + 1) / ks);
+  const int nk = it1 - it0;
+
+  // ---- DMA sources: per unit type j, wave w copies rows 16w .. 16w + 15 of the unit as two 8-row pieces.  The per-lane
+  // part of the address is a 32-bit byte offset that only changes with the output tile; everything that moves inside a
+  // tile (K position, tap) and the batch offset are wave-uniform and live in the 64-bit scalar cursors.
+  unsigned voff[4][2];
+  auto set_stage_tile = [&](int v) __attribute__((always_inline)) {
+    int tm, tn;
+    tile_of(v, tm, tn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ur = (wid * 2 + i) * 8 + (lane >> 3);       // row inside the unit
+        const int chunk = (lane & 7) ^ ((ur >> 1) & 7);        // source-side swizzle
+        if (j == 0 || j == 3) {                                // A: unit row = wave row (ur >> 5) x 32 rows of this m-half
+          int gm = tm * BM + (ur >> 5) * 64 + (j == 3 ? 32 : 0) + (ur & 31);
+          gm = gm < p.M ? gm : p.M - 1;
+          voff[j][i] = (unsigned)((long)gm * p.lda * 2 + chunk * 16);
+        } else {                                               // W: unit row = wave column (ur >> 6) x 64 rows of this n-half
+          int gn = tn * BN + (ur >> 6) * 128 + (j == 2 ? 64 : 0) + (ur & 63);
+          gn = gn < p.Npad ? gn : p.Npad - 1;
+          voff[j][i] = (unsigned)((long)gn * p.ldw * 2 + chunk * 16);
+        }
       }
-    } else if constexpr (SWIGLU) {
-      // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
+  };
+  // staging cursors (wave-uniform): A units j0, j3 of one K-tile share a_cur, W units j1, j2 share w_cur.  After the
+  // last K-tile of an output tile the stream moves on to the next tile of this workgroup; after the last tile the
+  // cursors stop, so the look-ahead units of the final phases re-stage the last K-tile into ring slots nobody reads
+  // again: every phase issues exactly two DMAs per wave and the counted vmcnt holds to the end.
+  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * 2;
+  const int kb0 = it0 % kb_per_tap;
+  const char* const a_start = (const char*)p.A + ((long)p.tap_base * p.lda + a_z + (long)(it0 / kb_per_tap) * p.tap_shift * p.lda) * 2 + (long)kb0 * KBYTES;
+  const char* const w_start = (const char*)p.W + w_z * 2 + (long)it0 * KBYTES;
+  const char* a_cur = a_start;
+  const char* w_cur = w_start;
+  int kb = kb0, kt_staged = 0, v_stage = blockIdx.x;
+  bool in_loop = false;
+  set_stage_tile(v_stage);
+  auto issue_unit = [&](auto jc, int buf) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    char* dst = smem + buf * KTILE + j * UNIT + wid * 2048;
+    const char* base = (j == 0 || j == 3) ? a_cur : w_cur;
+    if (DIAG != 1 || !in_loop) {
+      glds16(base + voff[j][0], dst);
+      glds16(base + voff[j][1], dst + 1024);
+    }
+    if (j == 2 && kt_staged + 1 < nk) w_cur += KBYTES;
+    if (j == 3) {
+      if (kt_staged + 1 < nk) {
+        ++kt_staged;
+        a_cur += KBYTES;
+        if (++kb == kb_per_tap) { kb = 0; a_cur += a_tap_bytes; }
+      } else if (v_stage + G < ntiles) {       // wave-uniform: on to the first K-tile of this workgroup's next tile
+        v_stage += G;
+        set_stage_tile(v_stage);
+        kt_staged = 0; kb = kb0; a_cur = a_start; w_cur = w_start;
+      }
+    }
+  };
+
+  // ---- fragment read addresses: lane (r = lane & 15, g = lane >> 4) reads row r of a 16-row fragment, k-chunk g (+ 4)
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int c0 = ((fg ^ (fr >> 1)) & 7) << 4;                 // swizzled 16-byte chunk of k-half 0; k-half 1 is c0 ^ 64
+  const int a_rd0 = (wm * 32 + fr) * KBYTES + c0, a_rd1 = a_rd0 ^ 64;   // + unit j0 / j3, + 16 i rows
+  const int w_rd0 = (wn * 64 + fr) * KBYTES + c0, w_rd1 = w_rd0 ^ 64;   // + unit j1 / j2, + 16 jn rows
+
+  f32x4 acc[4][8];                 // [m fragment][n fragment]: lane holds C[m = 16 i + fr][n = 16 jn + 4 fg + r]
+  bf16x8 af[2][2], wf[2][4][2];    // A (i, k-half) of the current m-half; W (n-half, jn, k-half)
+
+  // ---- prologue: the first LEAD units; units 0 and 1 must have landed everywhere before phase 0 reads them
+#pragma unroll
+  for (int u = 0; u < LEAD; ++u) {
+    if ((u & 3) == 0) issue_unit(IC<0>{}, (u >> 2) & 1);
+    if ((u & 3) == 1) issue_unit(IC<1>{}, (u >> 2) & 1);
+    if ((u & 3) == 2) issue_unit(IC<2>{}, (u >> 2) & 1);
+    if ((u & 3) == 3) issue_unit(IC<3>{}, (u >> 2) & 1);
+  }
+  wait_vmcnt<2 * (LEAD - 2)>();
+  __builtin_amdgcn_s_barrier();
+  in_loop = true;
+  if constexpr (DIAG == 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { af[i][0] = af[i][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wf[0][i][0] = wf[0][i][1] = wf[1][i][0] = wf[1][i][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; }
+  }
+
+  // t = K-tile counter of this workgroup over ALL its output tiles (ring parity)
+  auto phase = [&](auto qc, int t) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;
+    const char* sb = smem + (t & 1) * KTILE;
+    // ---- load part: fragments first read in this phase
+    if constexpr (DIAG != 2 && (q == 0 || q == 1)) {
+      const char* wp = sb + (q == 0 ? 1 : 2) * UNIT;
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        wf[nh][jn][0] = *(const bf16x8*)(wp + w_rd0 + jn * 16 * KBYTES);
+        wf[nh][jn][1] = *(const bf16x8*)(wp + w_rd1 + jn * 16 * KBYTES);
+      }
+    }
+    if constexpr (q == 0) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIAG != 2 && (q == 0 || q == 2)) {
+      const char* ap = sb + (q == 0 ? 0 : 3) * UNIT;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i][0] = *(const bf16x8*)(ap + a_rd0 + i * 16 * KBYTES);
+        af[i][1] = *(const bf16x8*)(ap + a_rd1 + i * 16 * KBYTES);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage the unit LEAD phases ahead
+    {
+      constexpr int jj = (q + LEAD) & 3, dt = (q + LEAD) >> 2;
+      issue_unit(IC<jj>{}, (t + dt) & 1);
+    }
+    // ---- the units first read in the next phase have landed (this wave's part of them)
+    if constexpr (q != 2) wait_vmcnt<2 * (LEAD - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (DIAG == 3) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[i][0]), "v"(af[i][1]));
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) asm volatile("" :: "v"(wf[nh][jn][0]), "v"(wf[nh][jn][1]));
+    } else
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+          acc[2 * mh + i][4 * nh + jn] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][jn][kk], af[i][kk], acc[2 * mh + i][4 * nh + jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- epilogue pieces
+  float* const my = (float*)(smem + 2 * KTILE) + wid * 1024;     // this wave's private 16 x 64 fp32 transposition area
+  T* const C = (T*)p.C + c_z;
+  // 16 rows x 64 columns held as v[c][r] = X[row fr][col 16 c + 4 fg + r]  ->  fn(row, c8, y[8]) with
+  // y = X[row][8 c8 .. 8 c8 + 7], row = 8 it + lane / 8, c8 = lane % 8.  Same-wave LDS traffic is executed in order.
+  auto rows = [&](const f32x4 (&v)[4], auto&& fn) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr * 16 + ((c * 4 + fg) ^ fr)) * 4) = v[c];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+      const f32x4 a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
+      const f32x4 b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+      float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      fn(row, c8, y);
+    }
+  };
+
+  int tcount = 0;
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, n_tiles = 0;
+  if constexpr (DIAG == 5) t_start = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
-      for (int idx = tid; idx < 32 * (CPR / 2); idx += CF::NT) {
-        const int ml = idx / (CPR / 2), pc = idx % (CPR / 2);
-        const int b = pc >> 2, q = pc & 3;
-        const int m = mrow0 + ml;
-        const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
-        if (m >= p.M || j0 >= (p.N >> 1)) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + q) ^ ml)) * 4);
-        const f32x4 b4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + 4 + q) ^ ml)) * 4);
-        swiglu_tail<T>(p, m, j0, a4, b4, C);
+  for (int v = blockIdx.x; v < ntiles; v += G) {
+    int tile_m, tile_n;
+    tile_of(v, tile_m, tile_n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned long long t_l0 = 0;
+    if constexpr (DIAG == 5) t_l0 = __builtin_amdgcn_s_memtime();
+    if (wid >= 4) __builtin_amdgcn_s_barrier();   // stagger: G1 runs one barrier behind G0 through the K loop
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t, ++tcount) {
+      phase(IC<0>{}, tcount); phase(IC<1>{}, tcount); phase(IC<2>{}, tcount); phase(IC<3>{}, tcount);
+    }
+    if (wid < 4) __builtin_amdgcn_s_barrier();    // level again: both groups run their epilogues side by side
+    if constexpr (DIAG == 5) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_loop += n - t_l0; t_l0 = n; ++n_tiles; }
+
+    const int m_base = tile_m * BM + wm * 64;      // + 16 i + row
+    const int n_base = tile_n * BN + wn * 128;     // + 64 h + 8 c8 (W-row index of the accumulator columns)
+    if constexpr (DIAG == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (p.ksplit > 1) {
+      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
+      float* ws = (float*)p.ws + (long)split * tiles_m * BM * (long)p.Npad;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 v4[4] = {acc[i][4 * h], acc[i][4 * h + 1], acc[i][4 * h + 2], acc[i][4 * h + 3]};
+          rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
+            const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+            if (n0 < p.Npad) {
+              float* d = ws + (long)m * p.Npad + n0;
+              *(f32x4*)d = f32x4{y[0], y[1], y[2], y[3]};
+              *(f32x4*)(d + 4) = f32x4{y[4], y[5], y[6], y[7]};
+            }
+          });
+        }
+    } else if constexpr (SWIGLU) {
+      // W rows come in 32-row groups [16 x w1 | 16 x w3]: fragments jn = 2k, 2k + 1 of one lane are the (a, b) pairs
+      // of output columns 16 k + 4 fg + r (model.py:307); 64 output columns per wave
+      const int j_base = tile_n * (BN / 2) + wn * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = Num<T>::rnd(acc[i][2 * k][r]), bb = Num<T>::rnd(acc[i][2 * k + 1][r]);
+            v4[k][r] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
+          }
+        rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
+          const int m = m_base + 16 * i + row, j0 = j_base + 8 * c8;
+          if (m < p.M && j0 < (p.N >> 1)) *(uint4*)(C + (long)m * p.ldc + j0) = pack8_bf16(y);
+        });
       }
     } else if (p.qkv_mode) {
       const int D = p.qkv_D;
-      const int sec = (tile_n * BN) / D;           // the whole tile lies in one of q | k | v | gate (D % BN == 0)
+      const int sec = (tile_n * BN) / D;            // the whole tile lies in one of q | k | v | gate (D % 256 == 0)
       if (sec == 2) {
-        // V section: transposed store, 8 consecutive tokens of one d per thread
-#pragma unroll 1
-        for (int idx = tid; idx < BN * 4; idx += CF::NT) {
-          const int col = idx % BN, sg = idx / BN;
-          const int m = mrow0 + 8 * sg;
-          if (m >= p.M) continue;
-          float v8[8];
+        // V: Vt[b][h * 128 + d][token]; this wave holds 64 tokens x the 128 d of one head.  Per 16 d (fragment jn) the
+        // four token fragments go through the private area as [d][token] and leave as 8 tokens per lane.
+        const int hd_base = n_base - 2 * D;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int rw = 8 * sg + r;
-            v8[r] = Num<T>::rnd(slab[(rw * CPR + ((col >> 2) ^ rw)) * 4 + (col & 3)]);
-          }
-          const int hd = tile_n * BN + col - 2 * D;        // h * 128 + d
-          const int b = m / p.qkv_S, sidx = m - b * p.qkv_S;
-          T* dst = (T*)p.vt + (long)b * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
-          if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
-            *(typename Vec4<T>::raw*)dst = Vec4<T>::pack(v8);
-            *(typename Vec4<T>::raw*)(dst + 4) = Vec4<T>::pack(v8 + 4);
-          } else {
-            for (int r = 0; r < 8 && m + r < p.M; ++r) {
-              const int bb = (m + r) / p.qkv_S, ss = (m + r) - bb * p.qkv_S;
-              ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(v8[r]);
+        for (int jn = 0; jn < 8; ++jn) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) my[(4 * fg + r) * 64 + 16 * i + fr] = Num<T>::rnd(acc[i][jn][r]);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int dl = it * 8 + (lane >> 3), t8 = lane & 7;
+            const f32x4 a = *(const f32x4*)(my + dl * 64 + 8 * t8);
+            const f32x4 b = *(const f32x4*)(my + dl * 64 + 8 * t8 + 4);
+            const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const int m = tile_m * BM + wm * 64 + 8 * t8;
+            const int hd = hd_base + 16 * jn + dl;
+            if (m < p.M) {
+              const int bq = m / p.qkv_S, sidx = m - bq * p.qkv_S;
+              T* dst = (T*)p.vt + (long)bq * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
+              if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
+                *(uint4*)dst = pack8_bf16(y);
+              } else {
+                for (int e = 0; e < 8 && m + e < p.M; ++e) {
+                  const int bb = (m + e) / p.qkv_S, ss = (m + e) - bb * p.qkv_S;
+                  ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(y[e]);
+                }
+              }
             }
           }
         }
       } else {
-#pragma unroll 1
-        for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
-          const int ml = idx / CPR, chunk = idx % CPR;
-          const int m = mrow0 + ml;
-          const int n0 = tile_n * BN + chunk * 4;
-          const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
-          float y[4] = {Num<T>::rnd(a4[0]), Num<T>::rnd(a4[1]), Num<T>::rnd(a4[2]), Num<T>::rnd(a4[3])};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 yv[8];
+#pragma unroll
+          for (int jn = 0; jn < 8; ++jn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
           if (sec < 2) {
-            // 32 consecutive lanes hold the 128 columns of one (token, head): half-wave reduction of the squares
-            float ss = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+            // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
+            // lane, the other 96 in lanes fr + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
+            float ss = 0.f;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            for (int jn = 0; jn < 8; ++jn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ss += yv[jn][r] * yv[jn][r];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
             const float rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int nd = n0 - sec * D;                   // h * 128 + d
+            const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg + r)
+            const bool do_rope = (nd0 >> 7) < p.rope_heads;
+            const int m = m_base + 16 * i + fr;
+            const int pos = p.pos0 + m % p.qkv_S;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              y[i] = Num<T>::rnd(__fmul_rn(__fmul_rn(y[i], rs), vec_at<T>(p.qk_w, (long)sec * D + nd + i)));
-            if ((nd >> 7) < p.rope_heads) {
-              const int pos = p.pos0 + m % p.qkv_S;
-              const float2* rp = (const float2*)p.rope + (long)pos * 64 + ((nd & 127) >> 1);
+            for (int jn = 0; jn < 8; ++jn) {
+              const int d0 = 16 * jn + 4 * fg;
+              float w4[4];
+              Vec4<T>::unpack(*(const Vec4<T>::raw*)((const T*)p.qk_w + (long)sec * D + nd0 + d0), w4);
 #pragma unroll
-              for (int pr = 0; pr < 2; ++pr) {
-                const float2 cs = rp[pr];
-                const float a = y[2 * pr], bq = y[2 * pr + 1];
-                y[2 * pr] = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(bq, cs.y));
-                y[2 * pr + 1] = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(bq, cs.x));
+              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
+              if (do_rope) {
+                const float4 cs = *(const float4*)((const float2*)p.rope + (long)pos * 64 + (d0 >> 1));   // two (cos, sin) pairs
+                const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
+                yv[jn][0] = __fsub_rn(__fmul_rn(a0, cs.x), __fmul_rn(b0, cs.y));
+                yv[jn][1] = __fadd_rn(__fmul_rn(a0, cs.y), __fmul_rn(b0, cs.x));
+                yv[jn][2] = __fsub_rn(__fmul_rn(a1, cs.z), __fmul_rn(b1, cs.w));
+                yv[jn][3] = __fadd_rn(__fmul_rn(a1, cs.w), __fmul_rn(b1, cs.z));
               }
             }
           }
-          if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
+            rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
+              const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+              if (m < p.M && n0 < p.N) *(uint4*)(C + (long)m * p.ldc + n0) = pack8_bf16(y);
+            });
+          }
         }
       }
     } else {
+      // the tail is emitted once (runtime loop over the 8 pieces); the accumulators of piece 2 i + h are picked by
+      // static register reads pinned with an empty asm (merged stores would turn `acc` into a scratch array)
 #pragma unroll 1
-      for (int idx = tid; idx < 32 * CPR; idx += CF::NT) {
-        const int ml = idx / CPR, chunk = idx % CPR;
-        const int m = mrow0 + ml;
-        const int n0 = tile_n * BN + chunk * 4;
-        if (m >= p.M || n0 >= p.N) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
-        float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-        gemm_tail<T>(p, m, n0, y, zo, zi, C, C2);
+      for (int piece = 0; piece < 8; ++piece) {
+        f32x4 v4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (piece == 2 * i + h) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { v4[c] = acc[i][4 * h + c]; asm volatile("" : "+v"(v4[c])); }
+            }
+        const int i_ = piece >> 1, h_ = piece & 1;
+        rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
+          const int m = m_base + 16 * i_ + row, n0 = n_base + 64 * h_ + 8 * c8;
+          if (m < p.M && n0 < p.N) gemm_tail8(p, m, n0, y, zo, zi, C);
+        });
       }
     }
+    if constexpr (DIAG == 5) t_epi += __builtin_amdgcn_s_memtime() - t_l0;
   }
+  if constexpr (DIAG == 5) {
+    if (lane == 0 && p.ws) {
+      unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 8;
+      o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_loop; o[2] = t_epi; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = n_tiles; o[7] = 0;
+    }
+  }
+  wait_vmcnt<0>();   // the re-staged look-ahead units must not land after the workgroup has released its LDS
 }
 
 // sums the split-K partial slabs in split order (deterministic) and applies the fused tail
@@ -497,6 +991,43 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   return hipGetLastError();
 }
 
+int pp_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    n &= ~7;                                   // a multiple of the 8 XCDs (tile_of)
+    if (const char* e = getenv("ECHO_PP_GRID")) { const int v = atoi(e); if (v >= 8) n = v & ~7; }
+  }
+  return n;
+}
+
+template <bool SW, int DIAG = 0, int LEAD = PP_LEAD>
+hipError_t launch_pp(const GemmArgs& g, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = gemm_pp_kernel<SW, DIAG, LEAD>;
+  constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.Npad + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int ks = g.ksplit > 1 ? g.ksplit : 1;
+  const int ncu = pp_num_cus();
+  dim3 grid(ntiles < ncu ? ntiles : ncu, g.nbatch, ks);   // persistent: one workgroup per CU walks the tile list
+  hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || ks == 1) return e;
+  const int Mpad = tiles_m * 256;
+  const long items = (long)g.M * (SW ? g.Npad / 8 : g.Npad / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, SW>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g, Mpad);
+  return hipGetLastError();
+}
+
 typedef TileCfg<128, 128, 2, 2, 2> Cfg0;   // 4 waves, 64 KiB: two workgroups per CU
 typedef TileCfg<128, 128, 2, 2, 4> Cfg1;   // 4 waves, 128 KiB, 3 tiles in flight: latency-bound small grids
 typedef TileCfg<256, 256, 2, 4, 2> Cfg2;   // 8 waves (128x64 each), 128 KiB: lowest L2 traffic per FLOP
@@ -516,6 +1047,29 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
       }
     }
   }
+  if (g.cfg == 5 || g.cfg >= 100) {
+    // 16-byte row stores / loads: every row pitch and column count the epilogue touches must be a multiple of 8
+    if ((g.N & 7) || (g.ldc & 7) || (g.res && (g.ldres & 7)) || (g.swiglu && (g.N & 15)) || (g.vec_mod & 7) || g.act == 2 ||
+        g.snake_alpha || g.C2 || !g.store_main ||
+        (g.qkv_mode && ((g.qkv_D & 255) || (g.vt_ld & 7))))
+      return hipErrorInvalidValue;
+  }
+  if (g.cfg == 5) {
+    if constexpr (Num<T>::is_bf16) return launch_pp<SW>(g, st);
+    else return hipErrorInvalidValue;   // the ping-pong kernel is bf16 only
+  }
+  if (g.cfg >= 100) {   // timing experiments (tools/bench_gemm.py --diag): wrong results by construction
+    if constexpr (Num<T>::is_bf16 && !SW) {
+      if (g.cfg == 101) return launch_pp<false, 1>(g, st);
+      if (g.cfg == 102) return launch_pp<false, 2>(g, st);
+      if (g.cfg == 103) return launch_pp<false, 3>(g, st);
+      if (g.cfg == 104) return launch_pp<false, 4>(g, st);
+      if (g.cfg == 105) return launch_pp<false, 5>(g, st);
+      if (g.cfg == 106) return launch_pp<false, 0, 6>(g, st);
+      if (g.cfg == 107) return launch_pp<false, 0, 4>(g, st);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (g.cfg) {
     case 1: return launch_cfg<T, SW, Cfg1>(g, st);
     case 2: return launch_cfg<T, SW, Cfg2>(g, st);
@@ -527,15 +1081,15 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-int gemm_tile_m(int cfg) { return cfg == 2 || cfg == 3 ? 256 : 128; }
-int gemm_num_cfgs() { return 5; }
+int gemm_tile_m(int cfg) { return cfg == 2 || cfg == 3 || cfg >= 5 ? 256 : 128; }
+int gemm_num_cfgs() { return 6; }
 
 template <typename T>
 hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   constexpr int KE = KBYTES / (int)sizeof(T);
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3) || g.cfg < 0 || g.cfg >= gemm_num_cfgs())
+      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 107)))
     return hipErrorInvalidValue;
   if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
     return hipErrorInvalidValue;

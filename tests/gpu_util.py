@@ -38,7 +38,7 @@ def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
 def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
          nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
          vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
-         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0):
+         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None):
     d = L.EchoGemmDesc()
     es = A.element_size()
     d.A = A.data_ptr() + a_offset_elems * es
@@ -57,7 +57,9 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     d.snake_alpha = ptr(snake_alpha)
     d.store_main, d.swiglu = store_main, swiglu
     d.cfg, d.ksplit, d.split3 = cfg, ksplit, split3
-    if ksplit > 1:
+    if ws is not None:
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    elif ksplit > 1:
         need = ksplit * ((M + 255) // 256 * 256) * d.Npad * 4
         ws = torch.empty((need,), dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = ws.data_ptr(), need

@@ -104,6 +104,21 @@ def test_euler_sampler_bf16_within_reference_noise(golden, tiny_models, tag, cas
     assert e < _bf16_budget(g, f"{tag}.bf16.euler.{case}", f"{tag}.f32.euler.{case}"), e
 
 
+@pytest.mark.parametrize("force", ["5,1", "2,1", "0,2"])
+def test_euler_sampler_bf16_with_forced_gemm_plans(golden, monkeypatch, force):
+    """The same sampler with every GEMM forced onto one tile kernel (5 = ping-pong 256x256 incl. its fused QKV / SwiGLU /
+    gate-residual epilogues; 2 = 256x256 one-barrier pipeline; 0 with split-K): all within the bf16 budget."""
+    monkeypatch.setenv("ECHO_GEMM_FORCE", force)
+    w = R.make_dit_weights(TINY, seed=0)
+    m = E.EchoDiT(TINY, {k: v.bfloat16() for k, v in w.items()}, dtype=torch.bfloat16, device=DEV)
+    g, tag, case = golden, "tinyb2", "cfg_default"
+    lat = E.sample_euler_cfg_independent_guidances(m, g[f"{tag}.spk"], g[f"{tag}.smask"].bool(), g[f"{tag}.ids"],
+                                                   g[f"{tag}.tmask"].bool(), rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"],
+                                                   **SAMPLER_CASES[case])
+    e = rms(lat, g[f"{tag}.f32.euler.{case}"])
+    assert e < _bf16_budget(g, f"{tag}.bf16.euler.{case}", f"{tag}.f32.euler.{case}"), e
+
+
 @pytest.mark.parametrize("case,opts,cont", [("plain", "cfg_default", False), ("cont_opts", "all_options", True)])
 def test_blockwise_sampler_f32(golden, tiny_models, case, opts, cont):
     g, m = golden, tiny_models["f32"]

@@ -325,6 +325,62 @@ def test_gemm_all_tile_configs_and_splitk(cfg, ksplit):
     assert (o3.double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("ksplit", [1, 2, 4])
+def test_gemm_pingpong_matches_torch(ksplit):
+    """gemm_pp_kernel (cfg 5: 256x256 tile, 16x16x32 MFMA, staggered wave groups): ragged M / N, short and long K,
+    bf16 epilogue, SwiGLU, and a dilated bf16 conv through the taps loop, against fp32 torch + the same rounding points."""
+    for (M, N, K) in ((300, 384, 512), (1000, 640, 2048), (256, 256, 64 * ksplit)):
+        A, W = rnd(M, K, dtype=torch.bfloat16), U.pad_rows(rnd(N, K, dtype=torch.bfloat16, seed=1))
+        bias, cs = rnd(N, dtype=torch.bfloat16, seed=2), rnd(N, dtype=torch.bfloat16, seed=3)
+        res = rnd(M, N, dtype=torch.bfloat16, seed=4)
+        out = res.clone()
+        U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias, colscale=cs, res=out, ldres=N, cfg=5, ksplit=ksplit)
+        y1 = (A.float() @ W[:N].float().T + bias.float()).bfloat16()
+        y = ((y1.float() * cs.float()).bfloat16().float() + res.float()).bfloat16()
+        # a different summation order may flip the bf16 rounding of the intermediate y1: allow 2 ulp of every rounding point
+        tol = 2.0 * 2.0 ** -7 * ((y1.float() * cs.float()).abs() + y.float().abs()) + 2e-3
+        err = (out.float() - y.float()).abs()
+        assert bool((err <= tol).all()), (M, N, K, float((err - tol).max()))
+    M, K, F = 300, 512, 192
+    A = rnd(M, K, dtype=torch.bfloat16)
+    w1, w3 = rnd(F, K, dtype=torch.bfloat16, seed=5, scale=0.1), rnd(F, K, dtype=torch.bfloat16, seed=6, scale=0.1)
+    Wp = U.pack_swiglu(w1, w3)
+    o2 = torch.zeros((M, F), dtype=torch.bfloat16, device=DEV)
+    U.gemm(A, Wp, o2, M=M, N=2 * F, K=K, lda=K, ldw=K, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=5, ksplit=ksplit)
+    a = (A.float() @ w1.float().T).bfloat16()
+    b = (A.float() @ w3.float().T).bfloat16()
+    U.bf16_close(o2, (torch.nn.functional.silu(a.float()).bfloat16().float() * b.float()).bfloat16(), ulps=2.0, atol=2e-3)
+    # bf16 dilated causal conv through the taps loop (tap boundaries move the A cursor)
+    T_, Ci, Co, k, dil = 333, 128, 96, 7, 3
+    x = rnd(1, Ci, T_, dtype=torch.bfloat16)
+    w = rnd(Co, Ci, k, seed=7, scale=0.1, dtype=torch.bfloat16)
+    ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double(), ((k - 1) * dil, 0)), w.double(), dilation=dil)[0].T
+    xcl = torch.zeros((64 + T_, Ci), device=DEV, dtype=torch.bfloat16)
+    xcl[64:] = x[0].T
+    Wg = U.pad_rows(w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous())
+    o3 = torch.zeros((T_, Co), device=DEV, dtype=torch.bfloat16)
+    U.gemm(xcl, Wg, o3, M=T_, N=Co, K=Ci, lda=Ci, ldw=k * Ci, ldc=Co, taps=k, tap_base=-(k - 1) * dil, tap_shift=dil,
+           a_offset_elems=64 * Ci, cfg=5, ksplit=ksplit)
+    U.bf16_close(o3, ref.float().bfloat16(), ulps=2.0, atol=2e-3)
+
+
+def test_gemm_pingpong_deterministic_and_exact_on_integers():
+    """Small-integer operands make every product and sum exact in fp32: the ping-pong kernel must reproduce the integer
+    result bit for bit at a sampler-sized shape, three launches in a row (guards the LDS ring synchronisation)."""
+    M, N, K = 1920, 2048, 2048
+    g = torch.Generator(device="cpu").manual_seed(11)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(DEV, torch.bfloat16)
+    W = torch.randint(-3, 4, (N, K), generator=g).to(DEV, torch.bfloat16)
+    ref = (A.float() @ W.float().T)
+    outs = []
+    for _ in range(3):
+        out = torch.zeros((M, N), dtype=torch.float32, device=DEV).bfloat16()
+        U.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, cfg=5)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], ref.bfloat16())
+
+
 @pytest.mark.parametrize("cfg", [0, 2, 4])
 def test_gemm_f32_split3_accuracy(cfg):
     """fp32 GEMM on 3 bf16 MFMAs per product: relative error ~1e-5 of the exact result (used by the DAC decoder)."""

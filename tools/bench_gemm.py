@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import gpu_util as U
 
-def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4), splits=(1, 2, 4, 8), split3=0):
+def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4, 5), splits=(1, 2, 4, 8), split3=0):
     A = (torch.randn((M + 256, K), device="cuda") * 0.5).to(dtype)
     W = (torch.randn(((N + 255) // 256 * 256, K), device="cuda") * 0.05).to(dtype)
     C = torch.zeros((M, N if not swiglu else N // 2), dtype=dtype, device="cuda")
@@ -34,7 +34,7 @@ def bench(M, N, K, dtype=torch.bfloat16, swiglu=0, iters=10, cfgs=(0, 1, 2, 3, 4
     print(f"{str(dtype)[6:]:8s} M={M:5d} N={N:6d} K={K:5d} sw={swiglu} best c{best[1]}k{best[2]} {best[0]*1e3:7.1f} us {tf(best[0]):7.1f} TF || {line}", flush=True)
 
 if __name__ == "__main__":
-    for M in (1920, 640):
+    for M in (7680, 3840, 2560, 1920, 1280, 640):
         bench(M, 8192, 2048)
         bench(M, 2048, 2048)
         bench(M, 11776, 2048, swiglu=1)

@@ -1,0 +1,25 @@
+"""In-kernel cycle accounting of the ping-pong GEMM (cfg 105 = correct kernel + s_memtime sums per wave)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import gpu_util as U
+
+for (M, N, K) in ((7680, 8192, 2048), (7680, 2048, 5888), (2560, 8192, 2048)):
+    A = (torch.rand((M + 256, K), device="cuda") * 2 - 1).to(torch.bfloat16)
+    W = (torch.rand(((N + 255) // 256 * 256, K), device="cuda") * 2 - 1).to(torch.bfloat16)
+    C = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    ws = torch.zeros((256 * 8 * 8,), dtype=torch.int64, device="cuda")
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, Npad=(N + 127) // 128 * 128)
+    for _ in range(3):
+        U.gemm(A, W, C, cfg=105, ws=ws, **kw)
+    torch.cuda.synchronize()
+    r = ws.view(256, 8, 8).double()
+    used = r[:, :, 6] > 0
+    names = ["total", "kloop", "epilogue"]
+    for grp, sl in (("G0 (waves 0-3)", slice(0, 4)), ("G1 (waves 4-7)", slice(4, 8))):
+        x = r[:, sl][used[:, sl]]
+        tiles = x[:, 6].mean().item()
+        line = f"M={M} N={N} K={K} {grp}: tiles/wg {tiles:.2f} |"
+        for i, n in enumerate(names):
+            line += f" {n} {x[:, i].mean().item() / tiles:9.0f}"
+        print(line + "  (cycles per tile, s_memtime ticks)", flush=True)
