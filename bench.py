@@ -12,9 +12,12 @@ synthetic (1, 2560, 80) latent.
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step runs `--concurrency` (default 2) independent utterances per GPU, each on its own HIP stream and engine context:
-requests are independent (handler.py:747-759), and two in flight fill the CUs that the single-row (M = 640) phases of
-one utterance leave idle (+9 % throughput measured; `--concurrency 1` gives the single-request number).
+A step runs `--batch` (default 4 = BASELINE config C3's per-GPU share: 32 utterances over 8 GPUs) independent
+utterances through ONE sampler call, using the reference sampler's own batch axis (inference.py:448-449: text ids
+(B, Tt), speaker latents (B, Ts, 80), one noise draw of (B, S, 80)): the EchoDiT GEMMs then see M = 3*B*640 rows in
+the CFG steps and B*640 in the others, which is what fills 256 CUs with 256x256 tiles.  `--batch 1` is the
+single-request configuration (C2 proper); its throughput is measured in the same run and reported as
+`single_request`.  `--concurrency` > 1 additionally runs several such calls on separate HIP streams / engine contexts.
 
 Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
 utterances); the only collective in the job is the start-up broadcast of the frozen weights from
@@ -146,10 +149,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--concurrency", type=int, default=2,
+    ap.add_argument("--concurrency", type=int, default=1,
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=4,
                     help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
@@ -214,17 +217,43 @@ def main() -> None:
         pr = model.get_profile()
         model.set_profiling(False)
         flops = dit_gemm_flops(nb)
-        ach = flops / (pr.ms_gemm_sum * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt<bf16> (EchoDiT linears)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "launches": pr.n_gemm, "avg_launch_us": round(1e3 * pr.ms_gemm_sum / max(pr.n_gemm, 1), 2),
-                    "flops_per_launch": flops / max(pr.n_gemm, 1)}
+        ach_all = flops / (pr.ms_gemm_sum * 1e-3) / 1e12
+        # dominant kernel: the gemm_pp_kernel launches of that call (engine-side HIP events on the launch stream)
+        ach = pr.flops_pp / (pr.ms_pp_sum * 1e-3) / 1e12 if pr.n_pp else 0.0
+        traffic, traffic_src = None, None
+        try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected inside this process)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+            traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm.json (2 x FETCH_SIZE + WRITE_SIZE, KiB, batch 4)"
+        except Exception:
+            pass
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (bf16 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "launches": pr.n_pp, "avg_launch_us": round(1e3 * pr.ms_pp_sum / max(pr.n_pp, 1), 2),
+                    "flops_per_launch": pr.flops_pp / max(pr.n_pp, 1),
+                    "all_linears": {"achieved": round(ach_all, 1), "launches": pr.n_gemm, "ms": round(pr.ms_gemm_sum, 2),
+                                    "note": "every gemm launch of the call incl. the small ones (in/out projections, modulation tables), algorithmic FLOPs of SURVEY.md 8d"}}
         dac.set_profiling(True)
         E.ae_decode(dac, pca, lat)
         dp = dac.get_profile()
         dac.set_profiling(False)
-        phases = {"sampler_ms": round(pr.ms_total, 2), "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
-                  "dac_decode_ms": round(dp.ms_total, 2), "dac_gemm_ms": round(dp.ms_gemm_sum, 2)}
+        phases = {"utterances_per_call": nb, "sampler_ms": round(pr.ms_total, 2), "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
+                  "dac_decode_ms_per_utterance": round(dp.ms_total, 2), "dac_gemm_ms_per_utterance": round(dp.ms_gemm_sum, 2)}
+    single = None
+    if rank == 0 and nb * conc > 1 and not args.no_roofline:
+        # the same engine on one utterance at a time (BASELINE config C2 proper), 1 warm-up + 3 timed
+        i1, t1, s1, m1 = ids[:1], tmask[:1], spk[:1], smask[:1]
+        ms = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            lat1 = E.sample_euler_cfg_independent_guidances(model, s1, m1, i1, t1, rng_seed=50 + i, **SAMPLER)
+            E.ae_decode(dac, pca, lat1)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0s))
+        best = sorted(ms[1:])[1]
+        single = {"value": round(AUDIO_S / (best * 1e-3), 3), "unit": "audio-s/s", "ms_per_utterance": round(best, 2),
+                  "workload": "C2: one utterance per sampler call (M = 1920 / 640 GEMM rows)"}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(host_threads())
@@ -241,7 +270,7 @@ def main() -> None:
                                    "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
                                    "EchoDiT bf16 + Fish S1-DAC decode fp32, random weights",
                        "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
-            "roofline": roofline, "cpu_baseline": cpu, "phases": phases,
+            "roofline": roofline, "cpu_baseline": cpu, "single_request": single, "phases": phases,
         }
         print(json.dumps(out))
     if world > 1:

@@ -80,26 +80,62 @@ __global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict_
 }
 
 // Decoder tail (autoencoder.py:994): causal conv k, C -> 1, then tanh.  x already has the Snake applied.
-__global__ void conv_out_tanh_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long T, int S, int C, int k,
-                                     const float* __restrict__ w, float bias) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  const int tl = (int)(t % S);
-  float acc = bias;
-  for (int kk = 0; kk < k; ++kk) {
-    const int dt = kk - (k - 1);
-    if (tl + dt < 0) continue;
-    const float* xr = x + (t + dt) * ldx;
-    const float* wr = w + kk * C;
-    float part = 0.f;
-    for (int c = 0; c < C; c += 4) {
-      const float4 xv = *(const float4*)(xr + c), wv = *(const float4*)(wr + c);
-      part = fmaf(xv.x, wv.x, part); part = fmaf(xv.y, wv.y, part);
-      part = fmaf(xv.z, wv.z, part); part = fmaf(xv.w, wv.w, part);
+// HBM-bound (T x C fp32 read once): 8 consecutive lanes share one input row (coalesced 16-byte loads), every lane
+// accumulates the k per-tap partial dot products of its columns, an 8-lane butterfly finishes them into LDS
+// d[row][tap], and the outputs of the block are y[t] = tanh(bias + sum_tap d[t - (k-1) + tap][tap]).
+constexpr int CO_ROWS = 128, CO_KMAX = 8, CO_NV = 4;
+__global__ void __launch_bounds__(256) conv_out_tanh_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long T, int S,
+                                                            int C, int k, const float* __restrict__ w, float bias) {
+  __shared__ float d[CO_ROWS][CO_KMAX];
+  const int R = CO_ROWS - (k - 1);                       // outputs per block
+  const long t0 = (long)blockIdx.x * R;
+  const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+  float4 wr[CO_KMAX][CO_NV];
+#pragma unroll
+  for (int kk = 0; kk < CO_KMAX; ++kk)
+#pragma unroll
+    for (int v = 0; v < CO_NV; ++v) {
+      const int c = (j + 8 * v) * 4;
+      wr[kk][v] = (kk < k && c < C) ? *(const float4*)(w + (long)kk * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    acc += part;
+#pragma unroll 1
+  for (int it = 0; it < CO_ROWS / 32; ++it) {
+    const int lr = it * 32 + g;
+    const long t = t0 - (k - 1) + lr;
+    float acc[CO_KMAX];
+#pragma unroll
+    for (int kk = 0; kk < CO_KMAX; ++kk) acc[kk] = 0.f;
+    if (t >= 0 && t < T) {
+#pragma unroll
+      for (int v = 0; v < CO_NV; ++v) {
+        const int c = (j + 8 * v) * 4;
+        if (c < C) {
+          const float4 xv = *(const float4*)(x + t * ldx + c);
+#pragma unroll
+          for (int kk = 0; kk < CO_KMAX; ++kk) {
+            acc[kk] = fmaf(xv.x, wr[kk][v].x, acc[kk]); acc[kk] = fmaf(xv.y, wr[kk][v].y, acc[kk]);
+            acc[kk] = fmaf(xv.z, wr[kk][v].z, acc[kk]); acc[kk] = fmaf(xv.w, wr[kk][v].w, acc[kk]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < CO_KMAX; ++kk) {
+      float a = acc[kk];
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (j == 0) d[lr][kk] = a;
+    }
   }
-  y[t] = tanhf(acc);
+  __syncthreads();
+  const int i = threadIdx.x;
+  const long t = t0 + i;
+  if (i < R && t < T) {
+    const int tl = (int)(t % S);
+    float a = bias;
+    for (int kk = 0; kk < k; ++kk)
+      if (tl + kk - (k - 1) >= 0) a += d[i + kk][kk];
+    y[t] = tanhf(a);
+  }
 }
 
 // inference.py:228 front: out[r][l] = lat[r][l] / latent_scale, zero padded to Lpad columns
@@ -139,8 +175,9 @@ hipError_t launch_dwconv_ln(const float* x, long ldx, float* y, long ldy, int T,
 }
 hipError_t launch_conv_out_tanh(const float* x, long ldx, float* y, long T, int S, int C, int k, const float* w, float bias,
                                 hipStream_t st) {
-  if (C % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(conv_out_tanh_kernel, grid1d(T), dim3(256), 0, st, x, ldx, y, T, S, C, k, w, bias);
+  if (C % 4 || C > 32 * CO_NV || k < 1 || k > CO_KMAX || (ldx & 3)) return hipErrorInvalidValue;
+  const int R = CO_ROWS - (k - 1);
+  hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((T + R - 1) / R)), dim3(256), 0, st, x, ldx, y, T, S, C, k, w, bias);
   return hipGetLastError();
 }
 hipError_t launch_pca_prep(const float* lat, float* out, long ldo, long rows, int L, int Lpad, float scale, hipStream_t st) {

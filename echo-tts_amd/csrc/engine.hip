@@ -88,6 +88,7 @@ struct EngineBase {
   bool profiling = false;
   echo_profile prof{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
+  std::vector<double> gemm_event_flops;   // > 0: a gemm_pp_kernel launch (plan cfg 5) with that many algorithmic FLOPs
   size_t gemm_events_used = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
@@ -301,6 +302,8 @@ struct Engine : EngineBase {
         CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
         gemm_events.emplace_back(a, b);
       }
+      if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
+      gemm_event_flops[gemm_events_used] = g.cfg == 5 ? 2.0 * g.M * g.N * g.K * g.taps * g.nbatch : 0.0;
       auto& e = gemm_events[gemm_events_used++];
       CK(hipEventRecord(e.first, st));
       CK(launch_gemm_nt<T>(g, st));
@@ -970,10 +973,13 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
   void collect_gemm_times() {
-    prof.ms_gemm_sum = 0.f; prof.n_gemm = 0;
+    prof.ms_gemm_sum = 0.f; prof.n_gemm = 0; prof.ms_pp_sum = 0.f; prof.n_pp = 0; prof.flops_pp = 0.0;
     for (size_t i = 0; i < gemm_events_used; ++i) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) == hipSuccess) { prof.ms_gemm_sum += ms; ++prof.n_gemm; }
+      if (hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) == hipSuccess) {
+        prof.ms_gemm_sum += ms; ++prof.n_gemm;
+        if (i < gemm_event_flops.size() && gemm_event_flops[i] > 0.0) { prof.ms_pp_sum += ms; ++prof.n_pp; prof.flops_pp += gemm_event_flops[i]; }
+      }
     }
   }
 
@@ -1092,6 +1098,8 @@ struct Engine : EngineBase {
         CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
         gemm_events.emplace_back(a, b);
       }
+      if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
+      gemm_event_flops[gemm_events_used] = 0.0;
       auto& e = gemm_events[gemm_events_used++];
       CK(hipEventRecord(e.first, st));
       CK(launch_gemm_nt<float>(g, st));

@@ -170,6 +170,10 @@ int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* 
 typedef struct {
   float ms_mod, ms_steps, ms_total;
   float ms_gemm_sum; int n_gemm;   /* sum / count of gemm_nt launch durations of the last profiled run */
+  /* the dominant kernel alone: gemm_pp_kernel launches (plan cfg 5) of that run, their HIP-event time on the launch
+     stream and their algorithmic FLOPs 2 * M * N * K * taps (bench.py "roofline") */
+  float ms_pp_sum; int n_pp;
+  double flops_pp;
 } echo_profile;
 int echo_set_profiling(echo_ctx* ctx, int on);
 int echo_get_profile(echo_ctx* ctx, echo_profile* out);
