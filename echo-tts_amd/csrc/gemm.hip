@@ -566,7 +566,8 @@ __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, flo
 
 // DIAG (timing experiments only): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 4 = no epilogue
 // (1-4 give wrong results); 5 = correct results + per-wave cycle sums (s_memtime) written to p.ws: {total, K loops,
-// epilogue, tiles} x 8 waves per workgroup
+// epilogue, tiles} x 8 waves per workgroup; 6 = correct results + per-wave, per-phase cycle sums {load part, wait at
+// barrier 1, MFMA part, wait at barrier 2} x 4 phases
 template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   typedef bf16_t T;
@@ -637,24 +638,36 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   int kb = kb0, kt_staged = 0, v_stage = blockIdx.x;
   bool in_loop = false;
   set_stage_tile(v_stage);
-  auto issue_unit = [&](auto jc, int buf) __attribute__((always_inline)) {
+  // SWITCH = false: the caller knows that this unit is not the last one of an output tile (the steady K loop), so the
+  // tile hand-over (new per-lane offsets, cursor reset) is compiled out of the hot path
+  auto issue_unit = [&](auto jc, int buf, auto swc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
+    constexpr bool SWITCH = decltype(swc)::value != 0;
     char* dst = smem + buf * KTILE + j * UNIT + wid * 2048;
     const char* base = (j == 0 || j == 3) ? a_cur : w_cur;
     if (DIAG != 1 || !in_loop) {
       glds16(base + voff[j][0], dst);
       glds16(base + voff[j][1], dst + 1024);
     }
-    if (j == 2 && kt_staged + 1 < nk) w_cur += KBYTES;
-    if (j == 3) {
-      if (kt_staged + 1 < nk) {
+    if constexpr (!SWITCH) {
+      if (j == 2) w_cur += KBYTES;
+      if (j == 3) {
         ++kt_staged;
         a_cur += KBYTES;
         if (++kb == kb_per_tap) { kb = 0; a_cur += a_tap_bytes; }
-      } else if (v_stage + G < ntiles) {       // wave-uniform: on to the first K-tile of this workgroup's next tile
-        v_stage += G;
-        set_stage_tile(v_stage);
-        kt_staged = 0; kb = kb0; a_cur = a_start; w_cur = w_start;
+      }
+    } else {
+      if (j == 2 && kt_staged + 1 < nk) w_cur += KBYTES;
+      if (j == 3) {
+        if (kt_staged + 1 < nk) {
+          ++kt_staged;
+          a_cur += KBYTES;
+          if (++kb == kb_per_tap) { kb = 0; a_cur += a_tap_bytes; }
+        } else if (v_stage + G < ntiles) {       // wave-uniform: on to the first K-tile of this workgroup's next tile
+          v_stage += G;
+          set_stage_tile(v_stage);
+          kt_staged = 0; kb = kb0; a_cur = a_start; w_cur = w_start;
+        }
       }
     }
   };
@@ -672,10 +685,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   // ---- prologue: the first LEAD units; units 0 and 1 must have landed everywhere before phase 0 reads them
 #pragma unroll
   for (int u = 0; u < LEAD; ++u) {
-    if ((u & 3) == 0) issue_unit(IC<0>{}, (u >> 2) & 1);
-    if ((u & 3) == 1) issue_unit(IC<1>{}, (u >> 2) & 1);
-    if ((u & 3) == 2) issue_unit(IC<2>{}, (u >> 2) & 1);
-    if ((u & 3) == 3) issue_unit(IC<3>{}, (u >> 2) & 1);
+    if ((u & 3) == 0) issue_unit(IC<0>{}, (u >> 2) & 1, IC<1>{});
+    if ((u & 3) == 1) issue_unit(IC<1>{}, (u >> 2) & 1, IC<1>{});
+    if ((u & 3) == 2) issue_unit(IC<2>{}, (u >> 2) & 1, IC<1>{});
+    if ((u & 3) == 3) issue_unit(IC<3>{}, (u >> 2) & 1, IC<1>{});
   }
   wait_vmcnt<2 * (LEAD - 2)>();
   __builtin_amdgcn_s_barrier();
@@ -688,10 +701,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   }
 
   // t = K-tile counter of this workgroup over ALL its output tiles (ring parity)
-  auto phase = [&](auto qc, int t) __attribute__((always_inline)) {
+  unsigned long long ph_acc[4][4] = {};   // DIAG 6: [phase][load part, wait at barrier 1 (+ lgkmcnt), MFMA part, wait at barrier 2]
+  auto phase = [&](auto qc, int t, auto swc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value;
     constexpr int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;
     const char* sb = smem + (t & 1) * KTILE;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    if constexpr (DIAG == 6) s0 = __builtin_amdgcn_s_memtime();
     // ---- load part: fragments first read in this phase
     if constexpr (DIAG != 2 && (q == 0 || q == 1)) {
       const char* wp = sb + (q == 0 ? 1 : 2) * UNIT;
@@ -714,12 +730,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     // ---- stage the unit LEAD phases ahead
     {
       constexpr int jj = (q + LEAD) & 3, dt = (q + LEAD) >> 2;
-      issue_unit(IC<jj>{}, (t + dt) & 1);
+      issue_unit(IC<jj>{}, (t + dt) & 1, swc);
     }
     // ---- the units first read in the next phase have landed (this wave's part of them)
     if constexpr (q != 2) wait_vmcnt<2 * (LEAD - 2)>();
+    if constexpr (DIAG == 6) s1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (DIAG == 6) s2 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     if constexpr (DIAG == 3) {
@@ -738,7 +756,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][jn][kk], af[i][kk], acc[2 * mh + i][4 * nh + jn], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIAG == 6) s3 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
+    if constexpr (DIAG == 6) {
+      s4 = __builtin_amdgcn_s_memtime();
+      ph_acc[q][0] += s1 - s0; ph_acc[q][1] += s2 - s1; ph_acc[q][2] += s3 - s2; ph_acc[q][3] += s4 - s3;
+    }
   };
 
   // ---- epilogue pieces
@@ -773,9 +796,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     unsigned long long t_l0 = 0;
     if constexpr (DIAG == 5) t_l0 = __builtin_amdgcn_s_memtime();
     if (wid >= 4) __builtin_amdgcn_s_barrier();   // stagger: G1 runs one barrier behind G0 through the K loop
+    // steady part: while K-tile t < nk - 2 is computed, the units staged (K-tiles t + 1, t + 2) all belong to this
+    // output tile; the last two K-tiles run the general copy whose look-ahead crosses into the next output tile
+    int t = 0;
 #pragma unroll 1
-    for (int t = 0; t < nk; ++t, ++tcount) {
-      phase(IC<0>{}, tcount); phase(IC<1>{}, tcount); phase(IC<2>{}, tcount); phase(IC<3>{}, tcount);
+    for (; t + 2 < nk; ++t, ++tcount) {
+      phase(IC<0>{}, tcount, IC<0>{}); phase(IC<1>{}, tcount, IC<0>{}); phase(IC<2>{}, tcount, IC<0>{}); phase(IC<3>{}, tcount, IC<0>{});
+    }
+#pragma unroll 1
+    for (; t < nk; ++t, ++tcount) {
+      phase(IC<0>{}, tcount, IC<1>{}); phase(IC<1>{}, tcount, IC<1>{}); phase(IC<2>{}, tcount, IC<1>{}); phase(IC<3>{}, tcount, IC<1>{});
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();    // level again: both groups run their epilogues side by side
     if constexpr (DIAG == 5) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_loop += n - t_l0; t_l0 = n; ++n_tiles; }
@@ -931,6 +961,15 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     }
     if constexpr (DIAG == 5) t_epi += __builtin_amdgcn_s_memtime() - t_l0;
   }
+  if constexpr (DIAG == 6) {
+    if (lane == 0 && p.ws) {
+      unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[q * 4 + e] = ph_acc[q][e];
+    }
+  }
   if constexpr (DIAG == 5) {
     if (lane == 0 && p.ws) {
       unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 8;
@@ -1065,6 +1104,7 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
       if (g.cfg == 103) return launch_pp<false, 3>(g, st);
       if (g.cfg == 104) return launch_pp<false, 4>(g, st);
       if (g.cfg == 105) return launch_pp<false, 5>(g, st);
+      if (g.cfg == 108) return launch_pp<false, 6>(g, st);
       if (g.cfg == 106) return launch_pp<false, 0, 6>(g, st);
       if (g.cfg == 107) return launch_pp<false, 0, 4>(g, st);
     }
@@ -1089,7 +1129,7 @@ hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   constexpr int KE = KBYTES / (int)sizeof(T);
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 107)))
+      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 108)))
     return hipErrorInvalidValue;
   if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
     return hipErrorInvalidValue;

@@ -23,3 +23,19 @@ for (M, N, K) in ((7680, 8192, 2048), (7680, 2048, 5888), (2560, 8192, 2048)):
         for i, n in enumerate(names):
             line += f" {n} {x[:, i].mean().item() / tiles:9.0f}"
         print(line + "  (cycles per tile, s_memtime ticks)", flush=True)
+
+# per-phase breakdown (cfg 108)
+M, N, K = 7680, 8192, 2048
+A = (torch.rand((M + 256, K), device="cuda") * 2 - 1).to(torch.bfloat16)
+W = (torch.rand(((N + 255) // 256 * 256, K), device="cuda") * 2 - 1).to(torch.bfloat16)
+C = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+ws = torch.zeros((256 * 8 * 16,), dtype=torch.int64, device="cuda")
+for _ in range(2):
+    U.gemm(A, W, C, cfg=108, ws=ws, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, Npad=N)
+torch.cuda.synchronize()
+r = ws.view(256, 8, 4, 4).double()
+nph = 32 * 3.75   # K-tiles per workgroup
+for grp, sl in (("G0", slice(0, 4)), ("G1", slice(4, 8))):
+    x = r[:, sl].mean(dim=(0, 1)) / nph
+    for q in range(4):
+        print(f"{grp} phase q{q}: load {x[q,0]:6.0f}  wait-bar1 {x[q,1]:6.0f}  mfma {x[q,2]:6.0f}  wait-bar2 {x[q,3]:6.0f}   (cycles per phase)")
