@@ -14,7 +14,7 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     kt = torch.randn((Lt + 128, 48 * D), device=dev).bfloat16(); vt_t = torch.randn((1, H, 128, pT), device=dev).bfloat16()
     ksp = torch.randn((Ls + 128, 48 * D), device=dev).bfloat16(); vt_s = torch.randn((1, H, 128, pSp), device=dev).bfloat16()
     out = torch.zeros((R * S, D), dtype=torch.bfloat16, device=dev)
-    rows = [[S] * R, [Lt, 0, Lt][:R], [Ls, Ls, 0][:R]]
+    rows = [[S] * R, ([Lt, 0, Lt] * R)[:R] if R % 3 == 0 else [Lt] * R, ([Ls, Ls, 0] * R)[:R] if R % 3 == 0 else [Ls] * R]
     nk = torch.tensor(rows, dtype=torch.int32, device=dev)
     d = L.EchoAttnDesc()
     d.Q, d.q_ld, d.q_row_stride = qkvg.data_ptr(), 4 * D, S * 4 * D
@@ -56,4 +56,4 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     print("   longest waves: barrier %.0f issue %.0f compute %.0f (cycles per tile)" % tuple((big[:, i] / big[:, 3]).mean() for i in range(3)))
 
 if __name__ == "__main__":
-    run(3); run(1)
+    run(12); run(3); run(4); run(1)
