@@ -74,6 +74,23 @@ class DacConfig:
     upsample_factors: Tuple[int, ...] = (2, 2)
     norm_eps: float = 1e-5
     rope_base: float = 10000.0
+    # encode path (speaker reference -> latents): Encoder + downsample + pre_module + RVQ; autoencoder.py:1144-1192
+    encoder_dim: int = 64
+    encoder_rates: Tuple[int, ...] = (2, 4, 8, 8)
+    encoder_transformer_layers: Tuple[int, ...] = (0, 0, 0, 4)
+    encoder_window: int = 512
+    encoder_block_size: int = 16384
+    n_codebooks: int = 9
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+    semantic_codebook_size: int = 4096
+
+    @property
+    def encoder_hop(self) -> int:
+        h = 1
+        for r in self.encoder_rates:
+            h *= r
+        return h
 
     @property
     def hop(self) -> int:
@@ -507,19 +524,19 @@ def window_mask(n: int, window: int) -> Tensor:
     return ((j >= (i - window + 1).clamp(min=0)) & (j <= i))[None, None]
 
 
-def post_module(w: Weights, cfg: DacConfig, z: Tensor, p: str = "quantizer.post_module") -> Tensor:
-    """WindowLimitedTransformer.forward, channels-first in/out.  autoencoder.py:786-802, 590-626, 663-717."""
+def window_transformer(w: Weights, p: str, z: Tensor, layers: int, h: int, hd: int, window: int, block_size: int,
+                       eps: float, rope_base: float) -> Tensor:
+    """WindowLimitedTransformer.forward with input_dim == dim, channels-first in/out.  autoencoder.py:786-802, 590-626, 663-717."""
     x = z.transpose(1, 2)
     b, s, _ = x.shape
     if f"{p}.freqs_cis" in w:
         cache = w[f"{p}.freqs_cis"][:s]
     else:
-        cache = ae_rope_cache(cfg.post_block_size, cfg.post_head_dim, cfg.rope_base)[:s]
-    mask = window_mask(s, cfg.post_window).to(x.device)
-    h, hd = cfg.post_heads, cfg.post_head_dim
-    for i in range(cfg.post_layers):
+        cache = ae_rope_cache(block_size, hd, rope_base)[:s]
+    mask = window_mask(s, window).to(x.device)
+    for i in range(layers):
         lp = f"{p}.layers.{i}"
-        xn = ae_rms_norm(x, w[f"{lp}.attention_norm.weight"], cfg.norm_eps)
+        xn = ae_rms_norm(x, w[f"{lp}.attention_norm.weight"], eps)
         q, k, v = F.linear(xn, w[f"{lp}.attention.wqkv.weight"]).split([h * hd, h * hd, h * hd], dim=-1)
         q = ae_rotate(q.view(b, s, h, hd), cache).transpose(1, 2)
         k = ae_rotate(k.view(b, s, h, hd), cache).transpose(1, 2)
@@ -527,12 +544,18 @@ def post_module(w: Weights, cfg: DacConfig, z: Tensor, p: str = "quantizer.post_
         y = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, attn_mask=mask)
         y = F.linear(y.transpose(1, 2).contiguous().view(b, s, h * hd), w[f"{lp}.attention.wo.weight"])
         hmid = x + y.mul_(w[f"{lp}.attention_layer_scale.gamma"])
-        hn = ae_rms_norm(hmid, w[f"{lp}.ffn_norm.weight"], cfg.norm_eps)
+        hn = ae_rms_norm(hmid, w[f"{lp}.ffn_norm.weight"], eps)
         f = F.linear(F.silu(F.linear(hn, w[f"{lp}.feed_forward.w1.weight"])) *
                      F.linear(hn, w[f"{lp}.feed_forward.w3.weight"]), w[f"{lp}.feed_forward.w2.weight"])
         x = hmid + f.mul_(w[f"{lp}.ffn_layer_scale.gamma"])
-    x = ae_rms_norm(x, w[f"{p}.norm.weight"], cfg.norm_eps)
+    x = ae_rms_norm(x, w[f"{p}.norm.weight"], eps)
     return x.transpose(1, 2)
+
+
+def post_module(w: Weights, cfg: DacConfig, z: Tensor, p: str = "quantizer.post_module") -> Tensor:
+    """quantizer.post_module / pre_module (same configuration).  autoencoder.py:1144-1161."""
+    return window_transformer(w, p, z, cfg.post_layers, cfg.post_heads, cfg.post_head_dim, cfg.post_window, cfg.post_block_size,
+                              cfg.norm_eps, cfg.rope_base)
 
 
 def convnext_block(w: Weights, p: str, x: Tensor) -> Tensor:
@@ -601,6 +624,129 @@ def ae_decode(w: Weights, cfg: DacConfig, pca: PCA, latent: Tensor, ae_dtype: to
 
 
 # ------------------------------------------------------------ host-side post-processing
+# ------------------------------------------------------------------- DAC encode (speaker reference -> latents)
+def dac_encoder(w: Weights, cfg: DacConfig, audio: Tensor, p: str = "encoder.block") -> Tensor:
+    """Encoder.forward, causal: conv k7 1->C; per block 3 ResidualUnits (dil 1, 3, 9), Snake, conv k = 2s stride s
+    (C/2 -> C), optional window-limited transformer (heads = C / 64, ffn = 3C); Snake; conv k3.  autoencoder.py:839-929."""
+    x = causal_conv1d(w, f"{p}.0", audio, 7)
+    ch = cfg.encoder_dim
+    n = len(cfg.encoder_rates)
+    for i, (r, nt) in enumerate(zip(cfg.encoder_rates, cfg.encoder_transformer_layers)):
+        ch *= 2
+        bp = f"{p}.{i + 1}.block"
+        for j, d in enumerate((1, 3, 9)):
+            x = residual_unit(w, f"{bp}.{j}", x, d)
+        x = snake(x, w[f"{bp}.3.alpha"])
+        x = causal_conv1d(w, f"{bp}.4", x, 2 * r, stride=r)
+        if nt > 0:
+            x = window_transformer(w, f"{bp}.5", x, nt, ch // 64, 64, cfg.encoder_window, cfg.encoder_block_size, cfg.norm_eps,
+                                   cfg.rope_base)
+    x = snake(x, w[f"{p}.{n + 1}.alpha"])
+    return causal_conv1d(w, f"{p}.{n + 2}", x, 3)
+
+
+def _wn_conv1x1(w: Weights, p: str, x: Tensor) -> Tensor:
+    """WNConv1d(kernel_size=1) on (B, C, T).  autoencoder.py:90-94."""
+    return F.conv1d(x, fold_weight_norm(w, p), w[f"{p}.bias"])
+
+
+def vq_forward(w: Weights, p: str, z: Tensor) -> Tuple[Tensor, Tensor]:
+    """VectorQuantize.forward (eval): in_proj, nearest L2-normalised code, straight-through value, out_proj.
+    Returns (z_q (B, D, T), indices (B, T)).  autoencoder.py:130-158."""
+    z_e = _wn_conv1x1(w, f"{p}.in_proj", z)
+    b, d, t = z_e.shape
+    enc = F.normalize(z_e.permute(0, 2, 1).reshape(b * t, d))
+    cb = F.normalize(w[f"{p}.codebook.weight"])
+    dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
+    idx = (-dist).max(1)[1].view(b, t)
+    z_q = F.embedding(idx, w[f"{p}.codebook.weight"]).transpose(1, 2)
+    z_q = z_e + (z_q - z_e)
+    return _wn_conv1x1(w, f"{p}.out_proj", z_q), idx
+
+
+def vq_from_code(w: Weights, p: str, idx: Tensor) -> Tensor:
+    """out_proj(codebook[idx]) for one quantizer.  autoencoder.py:142-143, 223-231."""
+    return _wn_conv1x1(w, f"{p}.out_proj", F.embedding(idx, w[f"{p}.codebook.weight"]).transpose(1, 2))
+
+
+@torch.inference_mode()
+def dac_encode_codes(w: Weights, cfg: DacConfig, audio: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """DAC.encode: pad to whole frames, Encoder, downsample (conv k = f stride f + ConvNeXt per factor), pre_module,
+    semantic VQ, residual VQ stack.  Returns codes (B, 1 + n_codebooks, T).  autoencoder.py:1080-1108, 451-464, 184-220."""
+    if audio.ndim == 2:
+        audio = audio.unsqueeze(1)
+    frame = cfg.encoder_hop
+    for f in cfg.upsample_factors:
+        frame *= f
+    length = audio.shape[-1]
+    audio = F.pad(audio, (0, math.ceil(length / frame) * frame - length))
+    z = dac_encoder(w, cfg, audio)
+    if taps is not None:
+        taps["encoder"] = z.clone()
+    for i, f in enumerate(cfg.upsample_factors):
+        z = causal_conv1d(w, f"quantizer.downsample.{i}.0", z, f, stride=f)
+        z = convnext_block(w, f"quantizer.downsample.{i}.1", z)
+    z = post_module(w, cfg, z, "quantizer.pre_module")
+    if taps is not None:
+        taps["pre_module"] = z.clone()
+    sem_z, sem_idx = vq_forward(w, "quantizer.semantic_quantizer.quantizers.0", z)
+    residual = z - sem_z
+    codes = [sem_idx]
+    for i in range(cfg.n_codebooks):
+        zq_i, idx_i = vq_forward(w, f"quantizer.quantizer.quantizers.{i}", residual)
+        residual = residual - zq_i
+        codes.append(idx_i)
+    return torch.stack(codes, dim=1)
+
+
+@torch.inference_mode()
+def dac_encode_zq(w: Weights, cfg: DacConfig, audio: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """DAC.encode_zq: codes -> sum of out_proj(codebook[code]) over the semantic and residual quantizers.  autoencoder.py:1117-1126."""
+    codes = dac_encode_codes(w, cfg, audio, taps)
+    if taps is not None:
+        taps["codes"] = codes.clone()
+    z_sem = 0.0 + vq_from_code(w, "quantizer.semantic_quantizer.quantizers.0", codes[:, 0].clamp(max=cfg.semantic_codebook_size - 1))
+    z_res = 0.0
+    for i in range(cfg.n_codebooks):
+        z_res = z_res + vq_from_code(w, f"quantizer.quantizer.quantizers.{i}", codes[:, 1 + i].clamp(max=cfg.codebook_size - 1))
+    return z_sem + z_res
+
+
+@torch.inference_mode()
+def ae_encode(w: Weights, cfg: DacConfig, pca: PCA, audio: Tensor) -> Tensor:
+    """inference.py:218-224: (B, 1, L) audio -> (B, T, 80) latents."""
+    z_q = dac_encode_zq(w, cfg, audio).float()
+    z_q = (z_q.transpose(1, 2) - pca.pca_mean) @ pca.pca_components.T
+    return z_q * pca.latent_scale
+
+
+@torch.inference_mode()
+def get_speaker_latent_and_mask(w: Weights, cfg: DacConfig, pca: PCA, audio: Tensor, max_speaker_latent_length: int = 6400,
+                                audio_chunk_size: int = 640 * 2048, pad_to_max: bool = False,
+                                divis_by_patch_size: Optional[int] = 4) -> Tuple[Tensor, Tensor]:
+    """inference.py:239-283: encode in 30 s chunks (each zero padded to a whole chunk), trim to the true length."""
+    factor = 2048
+    audio = audio[:, : max_speaker_latent_length * factor]
+    lat = []
+    for i in range(0, audio.shape[1], audio_chunk_size):
+        chunk = audio[:, i:i + audio_chunk_size]
+        if chunk.shape[1] < audio_chunk_size:
+            chunk = F.pad(chunk, (0, audio_chunk_size - chunk.shape[1]))
+        lat.append(ae_encode(w, cfg, pca, chunk.unsqueeze(0)))
+    speaker_latent = torch.cat(lat, dim=1)
+    actual = audio.shape[1] // factor
+    mask = (torch.arange(speaker_latent.shape[1]) < actual).unsqueeze(0)
+    if pad_to_max and speaker_latent.shape[1] < max_speaker_latent_length:
+        speaker_latent = F.pad(speaker_latent, (0, 0, 0, max_speaker_latent_length - speaker_latent.shape[1]))
+        mask = F.pad(mask, (0, max_speaker_latent_length - mask.shape[1]))
+    elif not pad_to_max:
+        speaker_latent, mask = speaker_latent[:, :actual], mask[:, :actual]
+    if divis_by_patch_size is not None:
+        n = speaker_latent.shape[1] // divis_by_patch_size * divis_by_patch_size
+        speaker_latent, mask = speaker_latent[:, :n], mask[:, :n]
+    return speaker_latent, mask
+
+
 def find_flattening_point(data: Tensor, target_value: float = 0.0, window_size: int = 20,
                           std_threshold: float = 0.05) -> int:
     """inference.py:288-296."""
@@ -763,6 +909,97 @@ def make_dac_weights(cfg: DacConfig, seed: int = 0) -> Weights:
     w[f"{dm}.{n + 1}.alpha"] = 1.0 + rnd(1, co, 1, std=0.2)
     wn_conv(f"{dm}.{n + 2}", 1, co, 7)
     return w
+
+
+def make_dac_encoder_weights(cfg: DacConfig, seed: int = 0) -> Weights:
+    """Seeded random encode-path DAC weights (Encoder, quantizer.downsample, pre_module, the VQ stacks) with the reference's
+    key names.  Drawn from their own generator so that the decode-path weights of make_dac_weights (and every fixture made
+    from them) stay what they were.  Unit-variance fan-in init, weight-norm gains around 0.7, codebooks of unit-scale rows."""
+    g = torch.Generator().manual_seed(seed + 4242)
+    w: Weights = {}
+
+    def rnd(*shape: int, std: float = 0.02) -> Tensor:
+        return torch.randn(shape, generator=g) * std
+
+    def lin(co: int, ci: int) -> Tensor:
+        return rnd(co, ci, std=1.0 / math.sqrt(ci))
+
+    def wn_conv(p: str, co: int, ci: int, k: int, gain: float = 0.7, sub: str = ".conv") -> None:
+        v = rnd(co, ci, k, std=1.0 / math.sqrt(ci * k))
+        w[f"{p}{sub}.parametrizations.weight.original1"] = v
+        w[f"{p}{sub}.parametrizations.weight.original0"] = gain * v.flatten(1).norm(dim=1).view(co, 1, 1) * \
+            (1.0 + 0.05 * torch.randn((co, 1, 1), generator=g))
+        w[f"{p}{sub}.bias"] = rnd(co)
+
+    def transformer(p: str, layers: int, d: int, nh: int, hd: int, ffn: int) -> None:
+        for i in range(layers):
+            lp = f"{p}.layers.{i}"
+            w[f"{lp}.attention.wqkv.weight"] = lin(3 * nh * hd, d)
+            w[f"{lp}.attention.wo.weight"] = lin(d, nh * hd)
+            w[f"{lp}.feed_forward.w1.weight"] = lin(ffn, d)
+            w[f"{lp}.feed_forward.w3.weight"] = lin(ffn, d)
+            w[f"{lp}.feed_forward.w2.weight"] = lin(d, ffn)
+            w[f"{lp}.ffn_norm.weight"] = 1.0 + rnd(d, std=0.1)
+            w[f"{lp}.attention_norm.weight"] = 1.0 + rnd(d, std=0.1)
+            w[f"{lp}.attention_layer_scale.gamma"] = 0.2 + rnd(d, std=0.05)
+            w[f"{lp}.ffn_layer_scale.gamma"] = 0.2 + rnd(d, std=0.05)
+        w[f"{p}.norm.weight"] = 1.0 + rnd(d, std=0.1)
+
+    ep = "encoder.block"
+    ch = cfg.encoder_dim
+    wn_conv(f"{ep}.0", ch, 1, 7, gain=1.5)
+    n = len(cfg.encoder_rates)
+    for i, (r, nt) in enumerate(zip(cfg.encoder_rates, cfg.encoder_transformer_layers)):
+        ci, ch = ch, ch * 2
+        bp = f"{ep}.{i + 1}.block"
+        for j in range(3):
+            rp = f"{bp}.{j}.block"
+            w[f"{rp}.0.alpha"] = 1.0 + rnd(1, ci, 1, std=0.2)
+            wn_conv(f"{rp}.1", ci, ci, 7)
+            w[f"{rp}.2.alpha"] = 1.0 + rnd(1, ci, 1, std=0.2)
+            wn_conv(f"{rp}.3", ci, ci, 1)
+        w[f"{bp}.3.alpha"] = 1.0 + rnd(1, ci, 1, std=0.2)
+        wn_conv(f"{bp}.4", ch, ci, 2 * r, gain=1.0)
+        if nt > 0:
+            transformer(f"{bp}.5", nt, ch, ch // 64, 64, 3 * ch)
+    w[f"{ep}.{n + 1}.alpha"] = 1.0 + rnd(1, ch, 1, std=0.2)
+    wn_conv(f"{ep}.{n + 2}", cfg.latent_dim, ch, 3, gain=1.0)
+    d = cfg.latent_dim
+    for i, f in enumerate(cfg.upsample_factors):
+        dn = f"quantizer.downsample.{i}"
+        w[f"{dn}.0.conv.weight"] = rnd(d, d, f, std=1.0 / math.sqrt(d * f))
+        w[f"{dn}.0.conv.bias"] = rnd(d)
+        w[f"{dn}.1.dwconv.conv.weight"] = rnd(d, 1, 7, std=0.3)
+        w[f"{dn}.1.dwconv.conv.bias"] = rnd(d)
+        w[f"{dn}.1.norm.weight"] = 1.0 + rnd(d, std=0.1)
+        w[f"{dn}.1.norm.bias"] = rnd(d)
+        w[f"{dn}.1.pwconv1.weight"] = lin(4 * d, d)
+        w[f"{dn}.1.pwconv1.bias"] = rnd(4 * d)
+        w[f"{dn}.1.pwconv2.weight"] = lin(d, 4 * d)
+        w[f"{dn}.1.pwconv2.bias"] = rnd(d)
+        w[f"{dn}.1.gamma"] = 0.3 + rnd(d, std=0.05)
+    transformer("quantizer.pre_module", cfg.post_layers, d, cfg.post_heads, cfg.post_head_dim, cfg.post_ffn)
+
+    def vq(p: str, size: int) -> None:
+        wn_conv(p, cfg.codebook_dim, d, 1, gain=1.0, sub=".in_proj")
+        wn_conv(p, d, cfg.codebook_dim, 1, gain=0.5, sub=".out_proj")
+        w[f"{p}.codebook.weight"] = rnd(size, cfg.codebook_dim, std=1.0)
+
+    vq("quantizer.semantic_quantizer.quantizers.0", cfg.semantic_codebook_size)
+    for i in range(cfg.n_codebooks):
+        vq(f"quantizer.quantizer.quantizers.{i}", cfg.codebook_size)
+    return w
+
+
+def make_test_audio(n_samples: int, seed: int = 11) -> Tensor:
+    """(1, 1, n) seeded test signal: a few gliding sinusoids + noise, amplitude ~0.2 (stands in for a speaker reference)."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n_samples, dtype=torch.float64) / 44100.0
+    x = torch.zeros(n_samples, dtype=torch.float64)
+    for f0, a in ((110.0, 0.12), (330.0, 0.06), (1250.0, 0.03)):
+        x += a * torch.sin(2 * math.pi * (f0 * t + 40.0 * t * t))
+    x = x.float() + 0.02 * torch.randn(n_samples, generator=g)
+    return x.view(1, 1, n_samples)
 
 
 def make_pca(cfg: DacConfig, latent_size: int = 80, seed: int = 0) -> PCA:

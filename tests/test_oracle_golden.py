@@ -134,3 +134,43 @@ def test_rescale_scalar_kat(golden):
     val = float(R.temporal_score_rescale(torch.tensor(1.0), torch.tensor(2.0), torch.tensor(0.5), 1.2, 3.0))
     assert val == golden["__meta__"]["host"]["rescale_scalar"]
     assert abs(val - 1.8824) < 1e-4
+
+
+# ----------------------------------------------------------------------- speaker-reference encode path
+def _enc_weights(cfg):
+    w = R.make_dac_weights(cfg, 0)
+    w.update(R.make_dac_encoder_weights(cfg, 0))
+    return w
+
+
+def test_dac_encode_tiny_bit_exact(golden):
+    """Encoder -> downsample -> pre_module -> semantic VQ + residual VQs -> from_codes, PCA, and the chunked
+    get_speaker_latent_and_mask: codes identical, every float output bit-identical to the reference's."""
+    from tests.golden_defs import TINY_ENC_SAMPLES
+    g, cfg = golden, TINY_DAC
+    w = _enc_weights(cfg)
+    audio = R.make_test_audio(TINY_ENC_SAMPLES, seed=11)
+    taps = {}
+    zq = R.dac_encode_zq(w, cfg, audio, taps)
+    assert torch.equal(taps["codes"], g["enc_tiny.codes"])
+    assert torch.equal(taps["encoder"][..., :8], g["enc_tiny.encoder_head"])
+    assert torch.equal(zq, g["enc_tiny.zq"])
+    pca = R.make_pca(cfg, 80, seed=0)
+    assert torch.equal(R.ae_encode(w, cfg, pca, audio), g["enc_tiny.ae_encode"])
+    lat, mask = R.get_speaker_latent_and_mask(w, cfg, pca, audio[0], max_speaker_latent_length=24, audio_chunk_size=4 * 2048)
+    assert torch.equal(lat, g["enc_tiny.spk_latent"])
+    assert torch.equal(mask.to(torch.uint8), g["enc_tiny.spk_mask"])
+
+
+def test_dac_encode_full_size_matches_reference(golden):
+    """Full-size Fish S1-DAC encode (4-layer window-512 encoder transformer over 600 positions, 8-layer pre_module, VQ 4096 +
+    9 x 1024) on 307 200 samples: codes identical, z_q and latents bit-identical."""
+    from tests.golden_defs import FULL_ENC_SAMPLES
+    g, cfg = golden, R.DacConfig()
+    w = _enc_weights(cfg)
+    audio = R.make_test_audio(FULL_ENC_SAMPLES, seed=11)
+    taps = {}
+    zq = R.dac_encode_zq(w, cfg, audio, taps)
+    assert torch.equal(taps["codes"], g["enc_full.codes"])
+    assert torch.equal(zq, g["enc_full.zq"])
+    assert torch.equal(R.ae_encode(w, cfg, R.make_pca(cfg, 80, seed=0), audio), g["enc_full.ae_encode"])

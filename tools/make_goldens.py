@@ -106,18 +106,28 @@ def build_ref_dac(ref_ae, cfg: R.DacConfig, weights):
             return ref_ae.WindowLimitedTransformer(causal=True, window_size=cfg.post_window,
                                                    input_dim=cfg.latent_dim, config=qcfg)
 
+        def tgc(**kw):   # the shape of build_ae's transformer_general_config (autoencoder.py:1163-1177)
+            return ref_ae.ModelArgs(block_size=kw.get("block_size", cfg.encoder_block_size), n_layer=kw.get("n_layer", 8),
+                                    n_head=kw.get("n_head", 8), dim=kw.get("dim", 512),
+                                    intermediate_size=kw.get("intermediate_size", 1536), n_local_heads=kw.get("n_local_heads", -1),
+                                    head_dim=kw.get("head_dim", 64), rope_base=kw.get("rope_base", 10000),
+                                    norm_eps=kw.get("norm_eps", 1e-5), dropout_rate=0.1, attn_dropout_rate=0.1, channels_first=True)
+
         q = ref_ae.DownsampleResidualVectorQuantize(
-            input_dim=cfg.latent_dim, n_codebooks=2, codebook_size=16, codebook_dim=8, quantizer_dropout=0.5,
-            downsample_factor=cfg.upsample_factors, semantic_codebook_size=16, pre_module=mk(), post_module=mk())
-        dac = ref_ae.DAC(encoder_dim=8, encoder_rates=[2, 4, 8, 8], latent_dim=cfg.latent_dim,
+            input_dim=cfg.latent_dim, n_codebooks=cfg.n_codebooks, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+            quantizer_dropout=0.5, downsample_factor=cfg.upsample_factors, semantic_codebook_size=cfg.semantic_codebook_size,
+            pre_module=mk(), post_module=mk())
+        dac = ref_ae.DAC(encoder_dim=cfg.encoder_dim, encoder_rates=list(cfg.encoder_rates), latent_dim=cfg.latent_dim,
                          decoder_dim=cfg.decoder_dim, decoder_rates=list(cfg.decoder_rates), quantizer=q,
-                         sample_rate=44100, causal=True, encoder_transformer_layers=[0, 0, 0, 0],
-                         decoder_transformer_layers=[0, 0, 0, 0], transformer_general_config=None)
+                         sample_rate=44100, causal=True, encoder_transformer_layers=list(cfg.encoder_transformer_layers),
+                         decoder_transformer_layers=[0, 0, 0, 0], transformer_general_config=tgc)
     res = dac.load_state_dict(weights, strict=False)
     assert not res.unexpected_keys, res.unexpected_keys
-    dec_missing = [k for k in res.missing_keys if k.startswith("decoder.") or k.startswith("quantizer.post_module.layers")
-                   or k.startswith("quantizer.upsample")]
-    assert not dec_missing, dec_missing
+    bad = [k for k in res.missing_keys if not (k.endswith("freqs_cis") or k.endswith("causal_mask"))]
+    need_enc = any(k.startswith("encoder.") for k in weights)
+    if not need_enc:
+        bad = [k for k in bad if k.startswith("decoder.") or k.startswith("quantizer.post_module.layers") or k.startswith("quantizer.upsample")]
+    assert not bad, bad[:10]
     return dac.eval()
 
 
@@ -214,6 +224,32 @@ def gen_dac(ref_ae, ref_inf, tag: str, cfg: R.DacConfig, out: dict, meta: dict, 
     meta[f"{tag}.wav_sha"] = sha(out[f"{tag}.wav"])
 
 
+def gen_dac_encode(ref_ae, ref_inf, tag: str, cfg: R.DacConfig, out: dict, meta: dict, n_samples: int, chunked: bool):
+    """Speaker-reference encode path: DAC.encode / encode_zq, ae_encode, get_speaker_latent_and_mask on seeded audio."""
+    w = R.make_dac_weights(cfg, seed=0)
+    w.update(R.make_dac_encoder_weights(cfg, seed=0))
+    meta[f"{tag}.enc_weights_digest"] = weights_digest({k: v for k, v in w.items() if k.startswith("encoder.") or "pre_module" in k
+                                                        or "downsample" in k or "quantizers" in k})
+    dac = build_ref_dac(ref_ae, cfg, w)
+    audio = R.make_test_audio(n_samples, seed=11)
+    meta[f"{tag}.audio_sha"] = sha(audio)
+    with torch.inference_mode():
+        z = dac.encoder(torch.nn.functional.pad(audio, (0, (-n_samples) % 2048)))
+        out[f"{tag}.encoder_head"] = z[..., :8].clone()
+        meta[f"{tag}.encoder_sha"] = sha(z)
+        codes, _ = dac.encode(audio)
+        out[f"{tag}.codes"] = codes.clone()
+        zq = dac.encode_zq(audio)
+        out[f"{tag}.zq"] = zq.clone()
+        pca = R.make_pca(cfg, 80, seed=0)
+        st = ref_inf.PCAState(pca_components=pca.pca_components, pca_mean=pca.pca_mean, latent_scale=pca.latent_scale)
+        out[f"{tag}.ae_encode"] = ref_inf.ae_encode(dac, st, audio).clone()
+        if chunked:
+            lat, mask = ref_inf.get_speaker_latent_and_mask(dac, st, audio[0], max_speaker_latent_length=24, audio_chunk_size=4 * 2048)
+            out[f"{tag}.spk_latent"] = lat.clone()
+            out[f"{tag}.spk_mask"] = mask.to(torch.uint8).clone()
+
+
 def gen_host(ref_inf, ref_handler, meta: dict):
     texts = [
         "Hello world.",
@@ -269,7 +305,25 @@ def gen_host(ref_inf, ref_handler, meta: dict):
     return post, (lat, lat2, lat3)
 
 
+def main_encode_only():
+    """`--encode`: only the speaker-reference encode fixtures (tests/golden/dac_encode.safetensors), merged into meta.json."""
+    from tests.golden_defs import TINY_ENC_SAMPLES, FULL_ENC_SAMPLES
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_model, ref_ae, ref_inf, ref_blk, ref_handler = import_reference()
+    meta = json.load(open(os.path.join(GOLD, "meta.json"), encoding="utf-8"))
+    out = {}
+    gen_dac_encode(ref_ae, ref_inf, "enc_tiny", TINY_DAC, out, meta, TINY_ENC_SAMPLES, chunked=True)
+    gen_dac_encode(ref_ae, ref_inf, "enc_full", R.DacConfig(), out, meta, FULL_ENC_SAMPLES, chunked=False)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLD, "dac_encode.safetensors"))
+    with open(os.path.join(GOLD, "meta.json"), "w", encoding="utf-8") as f:
+        json.dump(meta, f, indent=1, ensure_ascii=False)
+    print({k: tuple(v.shape) for k, v in out.items()})
+
+
 def main():
+    if "--encode" in sys.argv:
+        return main_encode_only()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_model, ref_ae, ref_inf, ref_blk, ref_handler = import_reference()
@@ -288,6 +342,12 @@ def main():
     out = {}
     gen_dac(ref_ae, ref_inf, "dac_tiny", TINY_DAC, out, meta, T=16)
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLD, "dac_tiny.safetensors"))
+
+    from tests.golden_defs import TINY_ENC_SAMPLES, FULL_ENC_SAMPLES
+    out = {}
+    gen_dac_encode(ref_ae, ref_inf, "enc_tiny", TINY_DAC, out, meta, TINY_ENC_SAMPLES, chunked=True)
+    gen_dac_encode(ref_ae, ref_inf, "enc_full", R.DacConfig(), out, meta, FULL_ENC_SAMPLES, chunked=False)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLD, "dac_encode.safetensors"))
 
     out = {}
     gen_dac(ref_ae, ref_inf, "dac_full", R.DacConfig(), out, meta, T=8)
