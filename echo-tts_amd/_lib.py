@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -35,6 +35,9 @@ class EchoConfig(C.Structure):
         ("dac_post_ffn", C.c_int), ("dac_post_window", C.c_int),
         ("dac_n_up", C.c_int), ("dac_up_factors", C.c_int * 4),
         ("dac_norm_eps", C.c_float),
+        ("dac_enc_dim", C.c_int), ("dac_enc_n_rates", C.c_int), ("dac_enc_rates", C.c_int * 8), ("dac_enc_tlayers", C.c_int * 8),
+        ("dac_enc_window", C.c_int),
+        ("dac_n_codebooks", C.c_int), ("dac_codebook_size", C.c_int), ("dac_codebook_dim", C.c_int), ("dac_semantic_size", C.c_int),
     ]
 
 
@@ -108,6 +111,9 @@ SIGNATURES = {
     "echo_dac_decode_zq": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "echo_set_pca": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "echo_dac_hop": (C.c_int, [vp]),
+    "echo_finalize_dac_encoder": (C.c_int, [vp, vp]),
+    "echo_dac_encode": (C.c_int, [vp, vp, C.c_long, vp, vp, vp, vp]),
+    "echo_set_pca_encode": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, vp]),
     "echo_op_gemm": (C.c_int, [C.c_int, C.POINTER(EchoGemmDesc), vp]),
     "echo_op_pack_rows": (C.c_int, [vp, C.c_int, c_i64, vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_op_attention_bf16": (C.c_int, [C.POINTER(EchoAttnDesc), vp]),

@@ -1,5 +1,5 @@
-"""HIP-backed Fish S1-DAC *decode* path with the reference's call surface (autoencoder.py:1128-1138:
-`DAC.decode_zq`, `.device`, `.dtype`).  The checkpoint keeps the reference's state-dict names; this
+"""HIP-backed Fish S1-DAC with the reference's call surface (autoencoder.py:1080-1138: `DAC.decode_zq`, `DAC.encode_zq`,
+`DAC.encode`, `.device`, `.dtype`): the decode path of the hot loop and the encode path of the speaker reference.  The checkpoint keeps the reference's state-dict names; this
 loader folds weight-norm (w = g * v / ||v||, autoencoder.py:90-94) and reshapes each Conv1d /
 ConvTranspose1d kernel into the GEMM form the HIP taps-GEMM consumes (channels-last activations).
 """
@@ -30,6 +30,22 @@ class DACConfig:
     norm_eps: float = 1e-5
     rope_base: float = 10000.0
     latent_size: int = 80
+    # encode path (speaker reference -> latents), autoencoder.py:1144-1192
+    encoder_dim: int = 64
+    encoder_rates: Tuple[int, ...] = (2, 4, 8, 8)
+    encoder_transformer_layers: Tuple[int, ...] = (0, 0, 0, 4)
+    encoder_window: int = 512
+    n_codebooks: int = 9
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+    semantic_codebook_size: int = 4096
+
+    @property
+    def frame_length(self) -> int:
+        h = 1
+        for r in tuple(self.encoder_rates) + tuple(self.upsample_factors):
+            h *= r
+        return h
 
     @classmethod
     def from_any(cls, o) -> "DACConfig":
@@ -103,6 +119,13 @@ class DAC:
         for i, f in enumerate(c.upsample_factors):
             cfg.dac_up_factors[i] = f
         cfg.dac_norm_eps = c.norm_eps
+        self._has_encoder = any(k.startswith("encoder.") for k in state_dict)
+        if self._has_encoder:
+            cfg.dac_enc_dim, cfg.dac_enc_n_rates, cfg.dac_enc_window = c.encoder_dim, len(c.encoder_rates), c.encoder_window
+            for i, (r, nt) in enumerate(zip(c.encoder_rates, c.encoder_transformer_layers)):
+                cfg.dac_enc_rates[i], cfg.dac_enc_tlayers[i] = r, nt
+            cfg.dac_n_codebooks, cfg.dac_codebook_size = c.n_codebooks, c.codebook_size
+            cfg.dac_codebook_dim, cfg.dac_semantic_size = c.codebook_dim, c.semantic_codebook_size
         ctx = C.c_void_p()
         L.check(self._lib.echo_ctx_create(C.byref(cfg), self._device.index or 0, C.byref(ctx)))
         self._ctx = ctx
@@ -116,6 +139,9 @@ class DAC:
         self._rope = cache.to(self._device)
         L.check(self._lib.echo_set_ae_rope_table(self._ctx, self._rope.data_ptr(), self._rope.shape[0]), self._ctx)
         self._pca_key = None
+        self._pca_enc_key = None
+        if self._has_encoder:
+            self._load_encoder(state_dict)
 
     def __del__(self):
         try:
@@ -187,6 +213,125 @@ class DAC:
         self._put(f"{dm}.{n + 2}.conv.bias", sd[f"{dm}.{n + 2}.conv.bias"])
         L.check(self._lib.echo_finalize_dac(self._ctx, self._stream()), self._ctx)
 
+    def _load_encoder(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Encode-path tensors under "enc.*": weight-norm folded, conv kernels in GEMM form (a stride-s conv with k = 2s
+        reads rows of s*Ci: its (Co, k*Ci) tap-major matrix is used as a 2-tap GEMM with K = s*Ci), codebooks L2-normalised
+        with the reference's own expression (F.normalize, autoencoder.py:148-149), from_codes operands concatenated."""
+        c = self.config
+        ep = "encoder.block"
+        self._put("enc.conv0.w", _fold(sd, f"{ep}.0.conv")[:, 0, :])
+        self._put("enc.conv0.b", sd[f"{ep}.0.conv.bias"])
+        n = len(c.encoder_rates)
+        tkeys = ("attention.wqkv.weight", "attention.wo.weight", "feed_forward.w1.weight", "feed_forward.w3.weight",
+                 "feed_forward.w2.weight", "ffn_norm.weight", "attention_norm.weight", "attention_layer_scale.gamma",
+                 "ffn_layer_scale.gamma")
+        for i, nt in enumerate(c.encoder_transformer_layers):
+            bp = f"{ep}.{i + 1}.block"
+            for j in range(3):
+                rp = f"{bp}.{j}.block"
+                self._put(f"enc.b{i}.ru{j}.a0", sd[f"{rp}.0.alpha"].flatten())
+                self._put(f"enc.b{i}.ru{j}.w7", _conv_as_gemm(_fold(sd, f"{rp}.1.conv")))
+                self._put(f"enc.b{i}.ru{j}.b7", sd[f"{rp}.1.conv.bias"])
+                self._put(f"enc.b{i}.ru{j}.a1", sd[f"{rp}.2.alpha"].flatten())
+                self._put(f"enc.b{i}.ru{j}.w1", _conv_as_gemm(_fold(sd, f"{rp}.3.conv")))
+                self._put(f"enc.b{i}.ru{j}.b1", sd[f"{rp}.3.conv.bias"])
+            self._put(f"enc.b{i}.alpha", sd[f"{bp}.3.alpha"].flatten())
+            self._put(f"enc.b{i}.wc", _conv_as_gemm(_fold(sd, f"{bp}.4.conv")))
+            self._put(f"enc.b{i}.bc", sd[f"{bp}.4.conv.bias"])
+            for l in range(nt):
+                for k in tkeys:
+                    self._put(f"enc.b{i}.t.layers.{l}.{k}", sd[f"{bp}.5.layers.{l}.{k}"])
+            if nt:
+                self._put(f"enc.b{i}.t.norm.weight", sd[f"{bp}.5.norm.weight"])
+        self._put("enc.final.alpha", sd[f"{ep}.{n + 1}.alpha"].flatten())
+        self._put("enc.final.w", _conv_as_gemm(_fold(sd, f"{ep}.{n + 2}.conv")))
+        self._put("enc.final.b", sd[f"{ep}.{n + 2}.conv.bias"])
+        for i in range(len(c.upsample_factors)):
+            dn = f"quantizer.downsample.{i}"
+            self._put(f"enc.down{i}.w", _conv_as_gemm(_fold(sd, f"{dn}.0.conv")))
+            self._put(f"enc.down{i}.b", sd[f"{dn}.0.conv.bias"])
+            self._put(f"enc.down{i}.dw", _fold(sd, f"{dn}.1.dwconv.conv"))
+            for src, dst in (("dwconv.conv.bias", "db"), ("norm.weight", "lnw"), ("norm.bias", "lnb"), ("pwconv1.weight", "p1w"),
+                             ("pwconv1.bias", "p1b"), ("pwconv2.weight", "p2w"), ("pwconv2.bias", "p2b"), ("gamma", "gamma")):
+                self._put(f"enc.down{i}.{dst}", sd[f"{dn}.1.{src}"])
+        pm = "quantizer.pre_module"
+        for l in range(c.post_layers):
+            for k in tkeys:
+                self._put(f"enc.pre.layers.{l}.{k}", sd[f"{pm}.layers.{l}.{k}"])
+        self._put("enc.pre.norm.weight", sd[f"{pm}.norm.weight"])
+        names = ["quantizer.semantic_quantizer.quantizers.0"] + [f"quantizer.quantizer.quantizers.{i}" for i in range(c.n_codebooks)]
+        fc_w, fc_b = [], 0.0
+        for q, p in enumerate(names):
+            cb = sd[f"{p}.codebook.weight"].float()
+            out_w = _fold(sd, f"{p}.out_proj")[:, :, 0]                      # (C, 8)
+            self._put(f"enc.vq{q}.in_w", _fold(sd, f"{p}.in_proj")[:, :, 0])  # (8, C)
+            self._put(f"enc.vq{q}.in_b", sd[f"{p}.in_proj.bias"])
+            self._put(f"enc.vq{q}.cbn", torch.nn.functional.normalize(cb))
+            self._put(f"enc.vq{q}.cb", cb)
+            self._put(f"enc.vq{q}.out_w", out_w)
+            self._put(f"enc.vq{q}.out_nb", -sd[f"{p}.out_proj.bias"].float())
+            fc_w.append(out_w)
+            fc_b = fc_b + sd[f"{p}.out_proj.bias"].float()
+        self._put("enc.fc.w", torch.cat(fc_w, dim=1))
+        self._put("enc.fc.b", fc_b)
+        L.check(self._lib.echo_finalize_dac_encoder(self._ctx, self._stream()), self._ctx)
+
+    # ------------------------------------------------------------------ encode (speaker reference)
+    def set_pca_encode(self, pca_state) -> None:
+        key = (id(pca_state.pca_components), id(pca_state.pca_mean), float(pca_state.latent_scale))
+        if key == self._pca_enc_key:
+            return
+        comp = pca_state.pca_components.detach().float().cpu()                       # (latent, C)
+        bias = -(pca_state.pca_mean.detach().double().cpu() @ comp.double().T).float()  # mean folded: (z - m) P^T = z P^T - m P^T
+        w = comp.contiguous().to(self._device)
+        b = bias.contiguous().to(self._device)
+        L.check(self._lib.echo_set_pca_encode(self._ctx, w.data_ptr(), b.data_ptr(), float(pca_state.latent_scale), 1, self._stream()),
+                self._ctx)
+        self._pca_enc_key = key
+
+    def _encode_raw(self, audio_data: torch.Tensor, want_latent: bool):
+        if not self._has_encoder:
+            raise L.EchoHipError("this DAC was loaded without encoder weights")
+        a = audio_data.to(self._device, torch.float32)
+        if a.ndim == 2:
+            a = a.unsqueeze(1)
+        assert a.ndim == 3 and a.shape[1] == 1, "audio must be (B, 1, length)"
+        B, _, n = a.shape
+        fl = self.config.frame_length
+        npad = -(-n // fl) * fl
+        a = torch.nn.functional.pad(a, (0, npad - n)).contiguous()               # autoencoder.py:1090-1092
+        T, c = npad // fl, self.config
+        nq = 1 + c.n_codebooks
+        codes = torch.empty((B, nq, T), dtype=torch.int32, device=self._device)
+        zq = torch.empty((B, T, c.latent_dim), dtype=torch.float32, device=self._device)
+        lat = torch.empty((B, T, c.latent_size), dtype=torch.float32, device=self._device) if want_latent else None
+        for b in range(B):
+            L.check(self._lib.echo_dac_encode(self._ctx, a[b].data_ptr(), npad, lat[b].data_ptr() if want_latent else None,
+                                              codes[b].data_ptr(), zq[b].data_ptr(), self._stream()), self._ctx)
+        return codes, zq, lat
+
+    @torch.no_grad()
+    def encode(self, audio_data: torch.Tensor, audio_lengths=None, n_quantizers=None, **kw):
+        """autoencoder.py:1080-1108: (B, 1, L) or (B, L) audio -> (codes (B, 1 + n_codebooks, T) int64, lengths)."""
+        codes, _, _ = self._encode_raw(audio_data, False)
+        n = audio_data.shape[-1]
+        fl = self.config.frame_length
+        lens = torch.full((codes.shape[0],), -(-n // fl), dtype=torch.long, device=self._device)
+        return codes.long(), lens
+
+    @torch.no_grad()
+    def encode_zq(self, audio_data: torch.Tensor) -> torch.Tensor:
+        """autoencoder.py:1117-1126: (B, 1, L) -> z_q (B, latent_dim, T)."""
+        _, zq, _ = self._encode_raw(audio_data, False)
+        return zq.transpose(1, 2)
+
+    @torch.no_grad()
+    def encode_latent(self, audio_data: torch.Tensor, pca_state) -> torch.Tensor:
+        """inference.py:218-224 in one engine call per item: (B, 1, L) -> (B, T, latent_size) fp32."""
+        self.set_pca_encode(pca_state)
+        _, _, lat = self._encode_raw(audio_data, True)
+        return lat
+
     def set_profiling(self, on: bool) -> None:
         L.check(self._lib.echo_set_profiling(self._ctx, int(on)), self._ctx)
 
@@ -227,5 +372,4 @@ class DAC:
             L.check(self._lib.echo_dac_decode_zq(self._ctx, z[b].data_ptr(), T, out[b].data_ptr(), self._stream()), self._ctx)
         return out
 
-    def encode_zq(self, audio_data: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("DAC encode is the next scope row (SURVEY.md §8f-1)")
+

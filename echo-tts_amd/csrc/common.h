@@ -194,3 +194,8 @@ hipError_t launch_conv_out_tanh(const float* x, long ldx, float* y, long T, int 
                                 float bias, hipStream_t st);
 hipError_t launch_pca_prep(const float* lat, float* out, long ldo, long rows, int L, int Lpad, float scale, hipStream_t st);
 hipError_t launch_snake_f32(const float* x, long ldx, float* y, long ldy, long rows, int C, const float* alpha, hipStream_t st);
+// encode path
+hipError_t launch_conv_in_snake(const float* x, long T, int C, int k, const float* w /*(C,k)*/, const float* b, const float* alpha,
+                                float* y, float* s, long ld, hipStream_t st);
+hipError_t launch_vq_argmax(const float* e, long lde, int T, const float* cbn, const float* cb, int size, int* idx, float* zst,
+                            long ld_zst, float* gath, long ld_g, hipStream_t st);

@@ -162,6 +162,91 @@ inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) /
 
 }  // namespace
 
+// ---------------------------------------------------------------- encode path (speaker reference -> latents)
+// Encoder head (autoencoder.py:917): causal conv k, 1 -> C on the raw audio; writes y[t][c] and the Snake of it with
+// the first ResidualUnit's alpha (the next GEMM's input).  One thread = 4 channels of one sample; HBM-bound on the stores.
+__global__ void __launch_bounds__(256) conv_in_snake_kernel(const float* __restrict__ x, long T, int C, int k, const float* __restrict__ w /*(C,k)*/,
+                                                            const float* __restrict__ b, const float* __restrict__ alpha,
+                                                            float* __restrict__ y, float* __restrict__ s, long ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = C / 4;
+  const long t = i / cpr;
+  if (t >= T) return;
+  const int c = (int)(i - t * cpr) * 4;
+  float acc[4] = {b[c], b[c + 1], b[c + 2], b[c + 3]};
+  for (int kk = 0; kk < k; ++kk) {
+    const long ts = t - (k - 1) + kk;
+    const float xv = ts >= 0 ? x[ts] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[(long)(c + e) * k + kk], xv, acc[e]);
+  }
+  float sn[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a = alpha[c + e], q = sinf(a * acc[e]);
+    sn[e] = acc[e] + (1.0f / (a + 1e-9f)) * (q * q);
+  }
+  *(float4*)(y + t * ld + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *(float4*)(s + t * ld + c) = make_float4(sn[0], sn[1], sn[2], sn[3]);
+}
+
+// VectorQuantize.decode_latents (autoencoder.py:145-158) for codebook_dim 8: one wave per row.  e (T, 8) projected
+// latents; cbn (size, 8) L2-normalised codebook, cb the raw one.  idx = first argmax of -(|e^|^2 - 2 e^.c^ + |c^|^2);
+// writes the code, the straight-through value e + (cb[idx] - e) into zst[t][0..7] (row pitch ld_zst, the out_proj GEMM
+// operand) and the raw code vector into gath[t][0..7] (row pitch ld_g, the from_codes GEMM operand).
+__global__ void __launch_bounds__(256) vq_argmax_kernel(const float* __restrict__ e, long lde, int T, const float* __restrict__ cbn,
+                                                        const float* __restrict__ cb, int size, int* __restrict__ idx_out,
+                                                        float* __restrict__ zst, long ld_zst, float* __restrict__ gath, long ld_g) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float ev[8], en[8];
+  float n2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { ev[d] = e[(long)t * lde + d]; n2 += ev[d] * ev[d]; }
+  const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+  float e2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { en[d] = ev[d] * inv; e2 += en[d] * en[d]; }
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < size; j += 64) {
+    const float4 c0 = *(const float4*)(cbn + (long)j * 8), c1 = *(const float4*)(cbn + (long)j * 8 + 4);
+    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    float dot = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { dot = fmaf(en[d], cv[d], dot); c2 = fmaf(cv[d], cv[d], c2); }
+    const float score = -((e2 - 2.0f * dot) + c2);
+    if (score > best) { best = score; bi = j; }      // strided scan keeps the lowest index of equal scores per lane
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane < 8) {
+    const float cvr = cb[(long)bi * 8 + lane];
+    const float evl = e[(long)t * lde + lane];
+    zst[(long)t * ld_zst + lane] = evl + (cvr - evl);
+    gath[(long)t * ld_g + lane] = cvr;
+  }
+  if (lane == 0) idx_out[t] = bi;
+}
+
+hipError_t launch_conv_in_snake(const float* x, long T, int C, int k, const float* w, const float* b, const float* alpha, float* y,
+                                float* s, long ld, hipStream_t st) {
+  if (C % 4 || (ld & 3)) return hipErrorInvalidValue;
+  const long n = T * (C / 4);
+  hipLaunchKernelGGL(conv_in_snake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, T, C, k, w, b, alpha, y, s, ld);
+  return hipGetLastError();
+}
+hipError_t launch_vq_argmax(const float* e, long lde, int T, const float* cbn, const float* cb, int size, int* idx, float* zst,
+                            long ld_zst, float* gath, long ld_g, hipStream_t st) {
+  hipLaunchKernelGGL(vq_argmax_kernel, dim3((T + 3) / 4), dim3(256), 0, st, e, lde, T, cbn, cb, size, idx, zst, ld_zst, gath, ld_g);
+  return hipGetLastError();
+}
+
 hipError_t launch_ae_rope(float* x, long ldx, int rows, int S, int H, int HD, const float* cache, hipStream_t st) {
   const long n = (long)rows * H * (HD / 2);
   hipLaunchKernelGGL(ae_rope_kernel, grid1d(n), dim3(256), 0, st, x, ldx, (long)rows, S, H, HD, cache);

@@ -116,6 +116,9 @@ struct EngineBase {
   virtual int dac_decode(const float* lat, int T, float scale, float* wav, hipStream_t st) = 0;
   virtual int dac_decode_zq(const float* z, int T, float* wav, hipStream_t st) = 0;
   virtual int set_pca(const float* w, const float* mean, int on_device, hipStream_t st) = 0;
+  virtual int finalize_dac_encoder(hipStream_t st) = 0;
+  virtual int dac_encode(const float* audio, long n, float* lat, int32_t* codes, float* zq, hipStream_t st) = 0;
+  virtual int set_pca_encode(const float* w, const float* bias, float scale, int on_device, hipStream_t st) = 0;
   virtual int debug_get_kv(int which, int layer, float* k, float* v, int* B, int* T) = 0;
 };
 
@@ -1135,6 +1138,280 @@ struct Engine : EngineBase {
   }
   int dac_decode_zq(const float* z, int Tn, float* wav, hipStream_t st) override { return dac_run(nullptr, z, Tn, 1.0f, wav, st); }
 
+  // WindowLimitedTransformer layers on channels-last x (Tn, C), in place; scratch: xn_buf, ao_buf (>= Tp*C + Tp*ff floats
+  // and Tn*C floats).  autoencoder.py:786-802, 590-626, 663-717.  The final RMSNorm is applied by the caller.
+  int dac_transformer(std::vector<DacLayer>& layers, float* x, int Tn, int C, int nh, int hd, int ff, int window, float* xn_buf,
+                      float* ao_buf, hipStream_t st) {
+    if (!ae_rope || Tn > ae_rope_npos) return fail("ae rope table missing or too short");
+    if (hd != 64 || C != nh * hd || ff % 64) return fail("unsupported transformer sizes");
+    const int Tp = (int)rup(Tn, 128);
+    const long ldq = 3L * nh * hd;
+    const int Tk = (int)rup(Tn, 32);
+    CK(b_dq.reserve((size_t)(Tp + 128) * ldq * sizeof(float)));
+    CK(b_dscore.reserve((size_t)nh * Tn * Tk * sizeof(float)));
+    CK(b_dvt.reserve((size_t)(nh + 1) * hd * rup(Tn, 64) * sizeof(float) + 128 * rup(Tn, 64) * sizeof(float)));
+    float *xn = xn_buf, *qkv = b_dq.as<float>(), *sc = b_dscore.as<float>(), *vt = b_dvt.as<float>(), *ao = ao_buf, *hh = xn_buf + (long)Tp * C;
+    const int vld = (int)rup(Tn, 64);
+    for (auto& L : layers) {
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.an, nullptr, st));
+      CKI(frun(FG(xn, C, L.wqkv, C, qkv, ldq, Tn, 3 * nh * hd, C), st));
+      CK(launch_ae_rope(qkv, ldq, Tn, Tn, nh, hd, ae_rope, st));
+      CK(launch_ae_rope(qkv + nh * hd, ldq, Tn, Tn, nh, hd, ae_rope, st));
+      CK(launch_transpose_heads<float>(qkv + 2 * nh * hd, ldq, vt, vld, 0, 1, Tn, nh, hd, st));
+      {
+        GemmArgs g = FG(qkv, ldq, qkv + nh * hd, ldq, sc, Tk, Tn, Tk, hd);
+        g.nbatch = nh; g.nbi = nh; g.a_bi = hd; g.w_bi = hd; g.c_bi = (long)Tn * Tk;
+        g.acc_scale = 1.0f / sqrtf((float)hd);
+        CKI(frun(g, st));
+      }
+      CK(launch_softmax_f32(sc, Tk, Tn, nh, Tn, Tk, nullptr, 0, 1, 1, window, st));
+      {
+        GemmArgs g = FG(sc, Tk, vt, vld, ao, C, Tn, hd, Tk);
+        g.nbatch = nh; g.nbi = nh; g.a_bi = (long)Tn * Tk; g.w_bi = (long)hd * vld; g.c_bi = hd;
+        CKI(frun(g, st));
+      }
+      { GemmArgs g = FG(ao, C, L.wo, nh * hd, x, C, Tn, C, nh * hd); g.colscale = L.ga; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.fn, nullptr, st));
+      { GemmArgs g = FG(xn, C, L.w13, C, hh, ff, Tn, 2 * ff, C); g.swiglu = 1; CKI(frun(g, st)); }
+      { GemmArgs g = FG(hh, ff, L.w2, ff, x, C, Tn, C, ff); g.colscale = L.gf; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+    }
+    return ECHO_OK;
+  }
+
+  // ------------------------------------------------------------------ Fish S1-DAC encode (speaker reference -> latents)
+  // inference.py:218-224 ae_encode -> DAC.encode_zq (autoencoder.py:1080-1126): Encoder (autoencoder.py:903-929), quantizer
+  // downsample + pre_module + semantic VQ + residual VQs (autoencoder.py:451-464, 184-220, 130-158), from_codes, PCA.
+  // Same building blocks as the decoder: channels-last fp32 rows, every conv a taps-GEMM (a stride-s conv with k = 2s reads
+  // the input as rows of s*Ci and becomes a 2-tap GEMM), Snake fused into the producing epilogue.
+  struct EncRU { float *a0, *w7, *b7, *a1, *w1, *b1; };
+  struct EncBlock { EncRU ru[3]; float *alpha, *wc, *bc; int ci, co, r; std::vector<DacLayer> tl; float* tnorm = nullptr; };
+  struct VQ { float *in_w, *in_b, *cbn, *cb, *out_w, *out_nb; int size; };
+  std::vector<EncBlock> eblocks;
+  std::vector<DacUp> ddowns;
+  std::vector<DacLayer> dpre; float* dpre_norm = nullptr;
+  std::vector<VQ> vqs;
+  float *econv0_w = nullptr, *econv0_b = nullptr, *efinal_alpha = nullptr, *econvL_w = nullptr, *econvL_b = nullptr;
+  float *fc_w = nullptr, *fc_b = nullptr, *pcae_w = nullptr, *pcae_b = nullptr, *pcae_scale = nullptr;
+  int fc_kpad = 0;
+  bool enc_ready = false, pcae_set = false;
+  DevBuf b_vq_e, b_vq_zst, b_vq_g, b_vq_idx;
+
+  int load_dac_layers(const std::string& pre, int layers, int C, int nh, int hd, int ff, std::vector<DacLayer>& out, float** fnorm,
+                      hipStream_t st) {
+    for (int i = 0; i < layers; ++i) {
+      const std::string lp = pre + ".layers." + std::to_string(i);
+      DacLayer L{};
+      CKI(fpack(lp + ".attention.wqkv.weight", &L.wqkv, rup(3 * nh * hd, 128), 3 * nh * hd, C, C, st));
+      CKI(fpack(lp + ".attention.wo.weight", &L.wo, rup(C, 128), C, nh * hd, nh * hd, st));
+      CKI(fpack(lp + ".feed_forward.w1.weight", &L.w13, rup(2 * ff, 128), ff, C, C, st, 0));
+      CKI(fpack(lp + ".feed_forward.w3.weight", &L.w13, rup(2 * ff, 128), ff, C, C, st, 1, &L.w13));
+      CKI(fpack(lp + ".feed_forward.w2.weight", &L.w2, rup(C, 128), C, ff, ff, st));
+      CKI(fvec(lp + ".attention_norm.weight", &L.an, C, st));
+      CKI(fvec(lp + ".ffn_norm.weight", &L.fn, C, st));
+      CKI(fvec(lp + ".attention_layer_scale.gamma", &L.ga, C, st));
+      CKI(fvec(lp + ".ffn_layer_scale.gamma", &L.gf, C, st));
+      out.push_back(L);
+    }
+    CKI(fvec(pre + ".norm.weight", fnorm, C, st));
+    return ECHO_OK;
+  }
+
+  int finalize_dac_encoder(hipStream_t st) override {
+    if (!dac_ready) return fail("echo_finalize_dac must be called first");
+    const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
+    const int C0 = cfg.dac_enc_dim, nr = cfg.dac_enc_n_rates, cd = cfg.dac_codebook_dim;
+    if (C0 <= 0 || C0 % 32 || nr < 1 || nr > 8 || cd != 8) return fail("unsupported DAC encoder sizes (channels % 32, codebook_dim 8)");
+    CKI(fpack("enc.conv0.w", &econv0_w, C0, C0, 7, 7, st));      // (C0, 7)
+    CKI(fvec("enc.conv0.b", &econv0_b, C0, st));
+    int ch = C0;
+    for (int i = 0; i < nr; ++i) {
+      EncBlock B{};
+      B.ci = ch; B.co = 2 * ch; B.r = cfg.dac_enc_rates[i];
+      const std::string bp = "enc.b" + std::to_string(i);
+      for (int j = 0; j < 3; ++j) {
+        const std::string rp = bp + ".ru" + std::to_string(j);
+        EncRU& ru = B.ru[j];
+        CKI(fvec(rp + ".a0", &ru.a0, B.ci, st));
+        CKI(fpack(rp + ".w7", &ru.w7, rup(B.ci, 128), B.ci, 7 * B.ci, 7 * B.ci, st));
+        CKI(fvec(rp + ".b7", &ru.b7, B.ci, st));
+        CKI(fvec(rp + ".a1", &ru.a1, B.ci, st));
+        CKI(fpack(rp + ".w1", &ru.w1, rup(B.ci, 128), B.ci, B.ci, B.ci, st));
+        CKI(fvec(rp + ".b1", &ru.b1, B.ci, st));
+      }
+      CKI(fvec(bp + ".alpha", &B.alpha, B.ci, st));
+      CKI(fpack(bp + ".wc", &B.wc, rup(B.co, 128), B.co, 2 * B.r * B.ci, 2L * B.r * B.ci, st));
+      CKI(fvec(bp + ".bc", &B.bc, B.co, st));
+      if (cfg.dac_enc_tlayers[i] > 0) {
+        if (B.co % 64) return fail("encoder transformer width must be a multiple of 64");
+        CKI(load_dac_layers(bp + ".t", cfg.dac_enc_tlayers[i], B.co, B.co / 64, 64, 3 * B.co, B.tl, &B.tnorm, st));
+      }
+      eblocks.push_back(B);
+      ch *= 2;
+    }
+    CKI(fvec("enc.final.alpha", &efinal_alpha, ch, st));
+    CKI(fpack("enc.final.w", &econvL_w, rup(C, 128), C, 3 * ch, 3L * ch, st));
+    CKI(fvec("enc.final.b", &econvL_b, C, st));
+    for (int i = 0; i < cfg.dac_n_up; ++i) {
+      const std::string dn = "enc.down" + std::to_string(i);
+      DacUp U{};
+      U.f = cfg.dac_up_factors[i];
+      CKI(fpack(dn + ".w", &U.w, rup(C, 128), C, U.f * C, (long)U.f * C, st));
+      CKI(fvec(dn + ".b", &U.b, C, st));
+      CKI(fpack(dn + ".dw", &U.dw, C, C, 7, 7, st));
+      CKI(fvec(dn + ".db", &U.db, C, st));
+      CKI(fvec(dn + ".lnw", &U.lnw, C, st));
+      CKI(fvec(dn + ".lnb", &U.lnb, C, st));
+      CKI(fpack(dn + ".p1w", &U.p1w, rup(4 * C, 128), 4 * C, C, C, st));
+      CKI(fvec(dn + ".p1b", &U.p1b, 4 * C, st));
+      CKI(fpack(dn + ".p2w", &U.p2w, rup(C, 128), C, 4 * C, 4 * C, st));
+      CKI(fvec(dn + ".p2b", &U.p2b, C, st));
+      CKI(fvec(dn + ".gamma", &U.gamma, C, st));
+      ddowns.push_back(U);
+    }
+    CKI(load_dac_layers("enc.pre", cfg.dac_post_layers, C, nh, hd, ff, dpre, &dpre_norm, st));
+    for (int q = 0; q <= cfg.dac_n_codebooks; ++q) {
+      const std::string vp = "enc.vq" + std::to_string(q);
+      VQ v{};
+      v.size = q == 0 ? cfg.dac_semantic_size : cfg.dac_codebook_size;
+      CKI(fpack(vp + ".in_w", &v.in_w, 128, cd, C, C, st));
+      CKI(fvec(vp + ".in_b", &v.in_b, cd, st));
+      CKI(fpack(vp + ".cbn", &v.cbn, v.size, v.size, cd, cd, st));
+      CKI(fpack(vp + ".cb", &v.cb, v.size, v.size, cd, cd, st));
+      CKI(fpack(vp + ".out_w", &v.out_w, rup(C, 128), C, cd, 32, st));      // K padded 8 -> 32
+      CKI(fvec(vp + ".out_nb", &v.out_nb, C, st));
+      vqs.push_back(v);
+    }
+    fc_kpad = (int)rup((cfg.dac_n_codebooks + 1) * cd, 32);
+    CKI(fpack("enc.fc.w", &fc_w, rup(C, 128), C, (cfg.dac_n_codebooks + 1) * cd, fc_kpad, st));
+    CKI(fvec("enc.fc.b", &fc_b, C, st));
+    CK(alloc_zero((void**)&pcae_w, (size_t)128 * C * sizeof(float)));
+    CK(alloc_zero((void**)&pcae_b, (size_t)128 * sizeof(float)));
+    CK(alloc_zero((void**)&pcae_scale, (size_t)128 * sizeof(float)));
+    CK(hipStreamSynchronize(st));
+    drop_raw({"enc."});
+    enc_ready = true;
+    return ECHO_OK;
+  }
+
+  int set_pca_encode(const float* w, const float* bias, float scale, int on_device, hipStream_t st) override {
+    if (!enc_ready) return fail("echo_finalize_dac_encoder was not called");
+    const int C = cfg.dac_latent_dim, Lz = cfg.latent_size;
+    if (Lz > 128 || (Lz & 3)) return fail("unsupported latent_size");
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    CK(hipMemcpyAsync(pcae_w, w, (size_t)Lz * C * sizeof(float), kind, st));
+    CK(hipMemcpyAsync(pcae_b, bias, (size_t)Lz * sizeof(float), kind, st));
+    std::vector<float> sc(128, scale);
+    CK(hipMemcpyAsync(pcae_scale, sc.data(), 128 * sizeof(float), hipMemcpyHostToDevice, st));
+    CK(hipStreamSynchronize(st));
+    pcae_set = true;
+    return ECHO_OK;
+  }
+
+  int dac_encode(const float* audio, long n, float* lat_out, int32_t* codes_out, float* zq_out, hipStream_t st) override {
+    if (!enc_ready) return fail("echo_finalize_dac_encoder was not called");
+    if (!pcae_set && lat_out) return fail("echo_set_pca_encode was not called");
+    const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
+    const int C0 = cfg.dac_enc_dim, cd = cfg.dac_codebook_dim;
+    long frame = 1;
+    for (auto& b : eblocks) frame *= b.r;
+    for (auto& d : ddowns) frame *= d.f;
+    if (n <= 0 || n % frame) return fail("audio length must be a positive multiple of the frame length");
+    if (n * C0 > (1L << 31) - 4096) return fail("audio chunk too long");
+    const long PADF = 64L * std::max(std::max(cfg.dac_decoder_dim, 4 * C), 16 * C0);
+    long maxel = std::max(n * (long)C0, (long)(n / frame) * 4L * 4 * C);
+    {
+      long rows = n; int ch = C0;
+      for (auto& b : eblocks) { rows /= b.r; ch *= 2; maxel = std::max(maxel, rows * (long)ch * 4); }   // transformer scratch: x4
+    }
+    const size_t bytes = (size_t)(maxel + PADF + 128L * 4 * C) * sizeof(float);
+    CK(b_dacA.reserve(bytes)); CK(b_dacB.reserve(bytes)); CK(b_dacC.reserve(bytes));
+    float *Y = b_dacA.as<float>() + PADF, *S = b_dacB.as<float>() + PADF, *U = b_dacC.as<float>() + PADF;
+    // ---- Encoder head: conv k7 1 -> C0, + Snake of the first ResidualUnit
+    CK(launch_conv_in_snake(audio, n, C0, 7, econv0_w, econv0_b, eblocks[0].ru[0].a0, Y, S, C0, st));
+    long rows = n;
+    const int dil[3] = {1, 3, 9};
+    for (size_t bi = 0; bi < eblocks.size(); ++bi) {
+      EncBlock& Bk = eblocks[bi];
+      const int ci = Bk.ci, co = Bk.co, r = Bk.r;
+      for (int j = 0; j < 3; ++j) {
+        EncRU& ru = Bk.ru[j];
+        {   // Snake -> conv k7 (dilated) -> Snake, only the Snake'd result is kept
+          GemmArgs g = FG(S, ci, ru.w7, 7L * ci, U, ci, rows, ci, ci);
+          g.taps = 7; g.tap_base = -6 * dil[j]; g.tap_shift = dil[j]; g.bias = ru.b7;
+          g.store_main = 0; g.C2 = U; g.snake_alpha = ru.a1;
+          CKI(frun(g, st));
+        }
+        {   // conv k1 + residual; second output = Snake with the next consumer's alpha
+          GemmArgs g = FG(U, ci, ru.w1, ci, Y, ci, rows, ci, ci);
+          g.bias = ru.b1; g.res = Y; g.ldres = ci;
+          g.store_main = j < 2 ? 1 : 0; g.C2 = S; g.snake_alpha = j < 2 ? Bk.ru[j + 1].a0 : Bk.alpha;
+          CKI(frun(g, st));
+        }
+      }
+      {   // conv k = 2r, stride r, ci -> co: rows of r*ci, taps {row j-1, row j}
+        const long rows2 = rows / r;
+        GemmArgs g = FG(S, (long)r * ci, Bk.wc, 2L * r * ci, Y, co, rows2, co, r * ci);
+        g.taps = 2; g.tap_base = -1; g.tap_shift = 1; g.bias = Bk.bc;
+        if (bi + 1 < eblocks.size() && Bk.tl.empty()) { g.C2 = U; g.snake_alpha = eblocks[bi + 1].ru[0].a0; }
+        CKI(frun(g, st));
+        rows = rows2;
+        if (g.C2) std::swap(S, U);
+      }
+      if (!Bk.tl.empty()) {
+        CKI(dac_transformer(Bk.tl, Y, (int)rows, co, co / 64, 64, 3 * co, cfg.dac_enc_window, S, U, st));
+        CK(launch_norm<float>(NORM_AE_RMS, Y, co, S, co, (int)rows, co, cfg.dac_norm_eps, Bk.tnorm, nullptr, st));
+        std::swap(Y, S);
+        if (bi + 1 < eblocks.size()) CK(launch_snake_f32(Y, co, S, co, rows, co, eblocks[bi + 1].ru[0].a0, st));
+      }
+    }
+    const int chL = eblocks.back().co;
+    CK(launch_snake_f32(Y, chL, S, chL, rows, chL, efinal_alpha, st));
+    {   // conv k3 -> latent_dim
+      GemmArgs g = FG(S, chL, econvL_w, 3L * chL, Y, C, rows, C, chL);
+      g.taps = 3; g.tap_base = -2; g.tap_shift = 1; g.bias = econvL_b;
+      CKI(frun(g, st));
+    }
+    // ---- quantizer.downsample: [conv k = f stride f ; ConvNeXt] (autoencoder.py:418-426, 360-373)
+    for (auto& D : ddowns) {
+      const long rows2 = rows / D.f;
+      { GemmArgs g = FG(Y, (long)D.f * C, D.w, (long)D.f * C, S, C, rows2, C, D.f * C); g.bias = D.b; CKI(frun(g, st)); }
+      rows = rows2;
+      CK(launch_dwconv_ln(S, C, U, C, (int)rows, (int)rows, C, D.dw, D.db, D.lnw, D.lnb, 1e-6f, st));
+      { GemmArgs g = FG(U, C, D.p1w, C, Y, 4L * C, rows, 4 * C, C); g.bias = D.p1b; g.act = 2; CKI(frun(g, st)); }
+      { GemmArgs g = FG(Y, 4L * C, D.p2w, 4L * C, S, C, rows, C, 4 * C); g.bias = D.p2b; g.colscale = D.gamma; g.res = S; g.ldres = C; CKI(frun(g, st)); }
+      std::swap(Y, S);
+    }
+    // ---- pre_module
+    const int Tn = (int)rows;
+    CKI(dac_transformer(dpre, Y, Tn, C, nh, hd, ff, cfg.dac_post_window, S, U, st));
+    CK(launch_norm<float>(NORM_AE_RMS, Y, C, S, C, Tn, C, cfg.dac_norm_eps, dpre_norm, nullptr, st));
+    std::swap(Y, S);
+    // ---- semantic VQ + residual VQs: residual <- residual - out_proj(straight-through code) after every quantizer
+    const int nq = (int)vqs.size();
+    CK(b_vq_e.reserve((size_t)(Tn + 256) * cd * sizeof(float)));
+    CK(b_vq_zst.reserve((size_t)(Tn + 256) * 32 * sizeof(float)));
+    CK(b_vq_g.reserve((size_t)(Tn + 256) * fc_kpad * sizeof(float)));
+    CK(b_vq_idx.reserve((size_t)nq * Tn * sizeof(int)));
+    float *e8 = b_vq_e.as<float>(), *zst = b_vq_zst.as<float>(), *gath = b_vq_g.as<float>();
+    int* idx = b_vq_idx.as<int>();
+    for (int q = 0; q < nq; ++q) {
+      VQ& v = vqs[q];
+      { GemmArgs g = FG(Y, C, v.in_w, C, e8, cd, Tn, cd, C); g.bias = v.in_b; CKI(frun(g, st)); }
+      CK(launch_vq_argmax(e8, cd, Tn, v.cbn, v.cb, v.size, idx + (long)q * Tn, zst, 32, gath + q * cd, fc_kpad, st));
+      { GemmArgs g = FG(zst, 32, v.out_w, 32, Y, C, Tn, C, 32); g.acc_scale = -1.0f; g.bias = v.out_nb; g.res = Y; g.ldres = C; CKI(frun(g, st)); }
+    }
+    // ---- encode_zq: sum over quantizers of out_proj(codebook[code]) as one GEMM over the gathered code vectors
+    { GemmArgs g = FG(gath, fc_kpad, fc_w, fc_kpad, S, C, Tn, C, fc_kpad); g.bias = fc_b; CKI(frun(g, st)); }
+    if (zq_out) CK(hipMemcpyAsync(zq_out, S, (size_t)Tn * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (codes_out) CK(hipMemcpyAsync(codes_out, idx, (size_t)nq * Tn * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (lat_out) {   // ((z_q - mean) @ P^T) * scale, mean folded into the bias (inference.py:221-223)
+      GemmArgs g = FG(S, C, pcae_w, C, lat_out, cfg.latent_size, Tn, cfg.latent_size, C);
+      g.bias = pcae_b; g.colscale = pcae_scale;
+      CKI(frun(g, st));
+    }
+    return ECHO_OK;
+  }
+
   // lat: (T, latent) latents (PCA applied here)  OR  zq: (T, C) channels-last quantizer output
   int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st) {
     if (!dac_ready) return fail("echo_finalize_dac was not called");
@@ -1172,36 +1449,7 @@ struct Engine : EngineBase {
       CK(hipMemcpyAsync(x, zq, (size_t)Tn * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     // ---- post_module: window-limited causal transformer (autoencoder.py:786-802)
-    const long ldq = 3L * nh * hd;
-    const int Tk = (int)rup(Tn, 32);
-    CK(b_dq.reserve((size_t)(Tp + 128) * ldq * sizeof(float)));
-    CK(b_dscore.reserve((size_t)nh * Tn * Tk * sizeof(float)));
-    CK(b_dvt.reserve((size_t)(nh + 1) * hd * rup(Tn, 64) * sizeof(float) + 128 * rup(Tn, 64) * sizeof(float)));
-    float *xn = bufS, *qkv = b_dq.as<float>(), *sc = b_dscore.as<float>(), *vt = b_dvt.as<float>(), *ao = bufU, *hh = bufS + (long)Tp * C;
-    const int vld = (int)rup(Tn, 64);
-    for (auto& L : dpost) {
-      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.an, nullptr, st));
-      CKI(frun(FG(xn, C, L.wqkv, C, qkv, ldq, Tn, 3 * nh * hd, C), st));
-      CK(launch_ae_rope(qkv, ldq, Tn, Tn, nh, hd, ae_rope, st));
-      CK(launch_ae_rope(qkv + nh * hd, ldq, Tn, Tn, nh, hd, ae_rope, st));
-      CK(launch_transpose_heads<float>(qkv + 2 * nh * hd, ldq, vt, vld, 0, 1, Tn, nh, hd, st));
-      {
-        GemmArgs g = FG(qkv, ldq, qkv + nh * hd, ldq, sc, Tk, Tn, Tk, hd);
-        g.nbatch = nh; g.nbi = nh; g.a_bi = hd; g.w_bi = hd; g.c_bi = (long)Tn * Tk;
-        g.acc_scale = 1.0f / sqrtf((float)hd);
-        CKI(frun(g, st));
-      }
-      CK(launch_softmax_f32(sc, Tk, Tn, nh, Tn, Tk, nullptr, 0, 1, 1, cfg.dac_post_window, st));
-      {
-        GemmArgs g = FG(sc, Tk, vt, vld, ao, C, Tn, hd, Tk);
-        g.nbatch = nh; g.nbi = nh; g.a_bi = (long)Tn * Tk; g.w_bi = (long)hd * vld; g.c_bi = hd;
-        CKI(frun(g, st));
-      }
-      { GemmArgs g = FG(ao, C, L.wo, nh * hd, x, C, Tn, C, nh * hd); g.colscale = L.ga; g.res = x; g.ldres = C; CKI(frun(g, st)); }
-      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.fn, nullptr, st));
-      { GemmArgs g = FG(xn, C, L.w13, C, hh, ff, Tn, 2 * ff, C); g.swiglu = 1; CKI(frun(g, st)); }
-      { GemmArgs g = FG(hh, ff, L.w2, ff, x, C, Tn, C, ff); g.colscale = L.gf; g.res = x; g.ldres = C; CKI(frun(g, st)); }
-    }
+    CKI(dac_transformer(dpost, x, Tn, C, nh, hd, ff, cfg.dac_post_window, bufS, bufU, st));
     CK(launch_norm<float>(NORM_AE_RMS, x, C, bufS, C, Tn, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
     // ---- quantizer.upsample: [ConvT k=f s=f ; ConvNeXt] (autoencoder.py:427-435, 360-373)
     float* cur = bufS;      // (rows, C)
@@ -1376,6 +1624,13 @@ int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, voi
 }
 int echo_set_pca(echo_ctx* ctx, const float* w, const float* mean, int on_device, void* stream) {
   return ctx ? ctx->eng->set_pca(w, mean, on_device, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_finalize_dac_encoder(echo_ctx* ctx, void* stream) { return ctx ? ctx->eng->finalize_dac_encoder((hipStream_t)stream) : ECHO_ERR; }
+int echo_dac_encode(echo_ctx* ctx, const float* audio, long n_samples, float* latent_out, int32_t* codes_out, float* zq_out, void* stream) {
+  return ctx ? ctx->eng->dac_encode(audio, n_samples, latent_out, codes_out, zq_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_set_pca_encode(echo_ctx* ctx, const float* w, const float* bias, float scale, int on_device, void* stream) {
+  return ctx ? ctx->eng->set_pca_encode(w, bias, scale, on_device, (hipStream_t)stream) : ECHO_ERR;
 }
 int echo_dac_hop(echo_ctx* ctx) {
   if (!ctx) return -1;

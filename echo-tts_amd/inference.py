@@ -118,8 +118,44 @@ def ae_decode(fish_ae: DAC, pca_state: PCAState, z_q: torch.Tensor) -> torch.Ten
 
 @torch.inference_mode()
 def ae_encode(fish_ae: DAC, pca_state: PCAState, audio: torch.Tensor) -> torch.Tensor:
-    raise NotImplementedError("DAC encode (speaker reference -> latents) is the next scope row (SURVEY.md §8f-1); "
-                              "pass precomputed speaker latents to the sampler")
+    """reference inference.py:218-224: (B, 1, length) audio -> (B, T, 80) latents (DAC.encode_zq + PCA projection)."""
+    assert audio.ndim == 3 and audio.shape[1] == 1
+    return fish_ae.encode_latent(audio, pca_state)
+
+
+@torch.inference_mode()
+def ae_reconstruct(fish_ae: DAC, pca_state: PCAState, audio: torch.Tensor) -> torch.Tensor:
+    """reference inference.py:231-235."""
+    return ae_decode(fish_ae, pca_state, ae_encode(fish_ae, pca_state, audio))
+
+
+@torch.inference_mode()
+def get_speaker_latent_and_mask(fish_ae: DAC, pca_state: PCAState, audio: torch.Tensor, max_speaker_latent_length: int = 6400,
+                                audio_chunk_size: int = 640 * 2048, pad_to_max: bool = False,
+                                divis_by_patch_size: int | None = 4) -> Tuple[torch.Tensor, torch.Tensor]:
+    """reference inference.py:239-283: (1, length) audio -> (speaker_latent (1, T, 80), mask (1, T)); the audio is encoded in
+    chunks of `audio_chunk_size` samples (each zero padded to a whole chunk, as in training), then trimmed to its true length."""
+    factor = 2048
+    assert audio.ndim == 2 and audio.shape[0] == 1
+    audio = audio[:, : max_speaker_latent_length * factor]
+    lat = []
+    for i in range(0, audio.shape[1], audio_chunk_size):
+        chunk = audio[:, i:i + audio_chunk_size]
+        if chunk.shape[1] < audio_chunk_size:
+            chunk = torch.nn.functional.pad(chunk, (0, audio_chunk_size - chunk.shape[1]))
+        lat.append(ae_encode(fish_ae, pca_state, chunk.unsqueeze(0)))
+    speaker_latent = torch.cat(lat, dim=1)
+    actual = audio.shape[1] // factor
+    mask = (torch.arange(speaker_latent.shape[1], device=speaker_latent.device) < actual).unsqueeze(0)
+    if pad_to_max and speaker_latent.shape[1] < max_speaker_latent_length:
+        speaker_latent = torch.nn.functional.pad(speaker_latent, (0, 0, 0, max_speaker_latent_length - speaker_latent.shape[1]))
+        mask = torch.nn.functional.pad(mask, (0, max_speaker_latent_length - mask.shape[1]))
+    elif not pad_to_max:
+        speaker_latent, mask = speaker_latent[:, :actual], mask[:, :actual]
+    if divis_by_patch_size is not None:
+        n = speaker_latent.shape[1] // divis_by_patch_size * divis_by_patch_size
+        speaker_latent, mask = speaker_latent[:, :n], mask[:, :n]
+    return speaker_latent, mask
 
 
 def find_flattening_point(data: torch.Tensor, target_value: float = 0.0, window_size: int = 20, std_threshold: float = 0.05) -> int:
@@ -267,19 +303,23 @@ def sample_pipeline(
     speaker_latent: torch.Tensor | None = None,
     speaker_mask: torch.Tensor | None = None,
 ) -> Tuple[torch.Tensor, str]:
-    """`speaker_latent`/`speaker_mask` (extension): precomputed reference-voice latents, since the DAC *encoder* is not
-    part of this round's scope; `speaker_audio` other than None raises until it is."""
+    """`speaker_audio` (1, length) goes through the HIP DAC encoder (get_speaker_latent_and_mask) like the reference;
+    `speaker_latent`/`speaker_mask` (extension) pass precomputed reference-voice latents instead (per-voice cache)."""
     MAX_TEXT_LENGTH = 768
     device, dtype = model.device, model.dtype
     ids, tmask, norm = get_text_input_ids_and_mask(
         [text_prompt], max_length=min(pad_to_max_text_length or MAX_TEXT_LENGTH, MAX_TEXT_LENGTH), device=device,
         normalize=normalize_text, return_normalized_text=True, pad_to_max=(pad_to_max_text_length is not None))
     if speaker_latent is None:
-        if speaker_audio is not None:
-            raise NotImplementedError("speaker_audio needs the DAC encoder (next scope row); pass speaker_latent/speaker_mask")
-        n = pad_to_max_speaker_latent_length or 4
-        speaker_latent = torch.zeros((1, n, model.config.latent_size), device=device, dtype=dtype)
-        speaker_mask = torch.zeros((1, n), device=device, dtype=torch.bool)
+        if speaker_audio is not None:       # reference inference.py:333-340
+            speaker_latent, speaker_mask = get_speaker_latent_and_mask(
+                fish_ae, pca_state, speaker_audio.to(device), max_speaker_latent_length=pad_to_max_speaker_latent_length or 6400,
+                pad_to_max=pad_to_max_speaker_latent_length is not None)
+            speaker_latent = speaker_latent.to(dtype)
+        else:
+            n = pad_to_max_speaker_latent_length or 4
+            speaker_latent = torch.zeros((1, n, model.config.latent_size), device=device, dtype=dtype)
+            speaker_mask = torch.zeros((1, n), device=device, dtype=torch.bool)
     latent_out = sample_fn(model, speaker_latent, speaker_mask, ids, tmask, rng_seed)
     audio_out = ae_decode(fish_ae, pca_state, latent_out)
     audio_out = crop_audio_to_flattening_point(audio_out, latent_out[0])

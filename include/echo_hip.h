@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 1
+#define ECHO_ABI_VERSION 2
 
 typedef struct echo_ctx echo_ctx;
 
@@ -44,6 +44,11 @@ typedef struct {
   int dac_post_layers, dac_post_heads, dac_post_head_dim, dac_post_ffn, dac_post_window;
   int dac_n_up, dac_up_factors[4];
   float dac_norm_eps;
+  /* DAC encode path (speaker reference -> latents; autoencoder.py:903-929, 376-464, 117-158): Encoder channel base,
+   * strides, transformer layers per block (window dac_enc_window, heads = C / 64, ffn = 3 C), VQ stack sizes.
+   * dac_enc_dim == 0: no encode path in this context. */
+  int dac_enc_dim, dac_enc_n_rates, dac_enc_rates[8], dac_enc_tlayers[8], dac_enc_window;
+  int dac_n_codebooks, dac_codebook_size, dac_codebook_dim, dac_semantic_size;
 } echo_config;
 
 int echo_abi_version(void);
@@ -60,6 +65,9 @@ int echo_load_tensor(echo_ctx* ctx, const char* name, const void* data, int dtyp
                      int data_on_device);
 int echo_finalize_dit(echo_ctx* ctx, void* stream);    /* pack EchoDiT weights for the kernels, drop the raw copies */
 int echo_finalize_dac(echo_ctx* ctx, void* stream);
+/* encode-path tensors ("enc.*", prepared by the Python loader: weight-norm folded, conv kernels in GEMM form, codebooks
+ * normalised, from_codes operands concatenated; INTEGRATION.md lists them).  Needs echo_finalize_dac first. */
+int echo_finalize_dac_encoder(echo_ctx* ctx, void* stream);
 
 /* Position tables computed by the host with the reference's own expressions (exactness for free):
  * rope: (npos, 64) float2 = (cos, sin) of model.py:9-14 for head_dim 128;
@@ -117,6 +125,14 @@ int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, voi
 /* inference.py:86-99 PCAState: w = pca_components transposed, (dac_latent_dim, latent_size) row-major fp32; mean (dac_latent_dim). */
 int echo_set_pca(echo_ctx* ctx, const float* w, const float* mean, int on_device, void* stream);
 int echo_dac_hop(echo_ctx* ctx);
+/* inference.py:218-224 ae_encode = DAC.encode_zq (autoencoder.py:1080-1126) + PCA projection, one item:
+ * audio (n_samples) fp32 device pointer, n_samples a multiple of the frame length (hop * 4 = 2048; the host pads);
+ * latent_out (T, latent_size) fp32, T = n_samples / frame; optional codes_out (1 + n_codebooks, T) int32 and
+ * zq_out (T, latent_dim) fp32 (channels-last) for parity checks.  PCA operands: echo_set_pca_encode. */
+int echo_dac_encode(echo_ctx* ctx, const float* audio, long n_samples, float* latent_out, int32_t* codes_out, float* zq_out,
+                    void* stream);
+/* w (latent_size, latent_dim) = pca_components, bias (latent_size) = -(pca_mean @ pca_components^T), scale = latent_scale */
+int echo_set_pca_encode(echo_ctx* ctx, const float* w, const float* bias, float scale, int on_device, void* stream);
 
 /* ---- single-kernel entry points (unit tests and micro-benchmarks; same kernels the engine launches) ---- */
 typedef struct {

@@ -28,8 +28,9 @@ WIDE1 = R.DiTConfig(num_layers=1, text_num_layers=1, speaker_num_layers=1)  # fu
 
 TINY_DAC = R.DacConfig(latent_dim=128, decoder_dim=512, decoder_rates=(8, 8, 4, 2), post_layers=2, post_heads=2,
                        post_head_dim=64, post_ffn=256, post_window=8, post_block_size=256, upsample_factors=(2, 2),
-                       # encode path (the reference hard-codes window 512 for the encoder transformer, autoencoder.py:855)
-                       encoder_dim=8, encoder_rates=(2, 4, 8, 8), encoder_transformer_layers=(0, 0, 0, 1), encoder_window=512,
+                       # encode path (the reference hard-codes window 512 for the encoder transformer, autoencoder.py:855; channel counts
+                       # are multiples of 32 = the fp32 GEMM K step of the HIP engine: 32 -> 64 -> 128 -> 256 -> 512)
+                       encoder_dim=32, encoder_rates=(2, 4, 8, 8), encoder_transformer_layers=(0, 0, 0, 1), encoder_window=512,
                        encoder_block_size=16384, n_codebooks=2, codebook_size=16, codebook_dim=8, semantic_codebook_size=16)
 TINY_ENC_SAMPLES = 2048 * 22 - 300        # 22 frames (padded), 88 encoder-transformer positions
 FULL_ENC_SAMPLES = 512 * 600              # 600 encoder-transformer positions (> window 512), 150 frames

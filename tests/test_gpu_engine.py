@@ -183,6 +183,67 @@ def test_dac_full_size_matches_reference(golden):
     assert rms(out, g["dac_full.ae_decode"]) < WAV_TOL
 
 
+# ----------------------------------------------------------------------- speaker-reference encode path
+def _enc_weights(cfg):
+    w = R.make_dac_weights(cfg, 0)
+    w.update(R.make_dac_encoder_weights(cfg, 0))
+    return w
+
+
+def _check_encode(g, tag, cfg, n_samples, min_code_match):
+    """codes: index work is bit-exact wherever the argmax is not a near-tie (the split3 fp32 GEMM sums in a different order
+    than the CPU reference, so a frame whose two best codes differ by ~1e-6 may flip; such a frame then carries a different
+    but equally near code vector); z_q / latents: compared on the frames whose codes all agree."""
+    dac = E.DAC(cfg, _enc_weights(cfg), device=DEV)
+    audio = R.make_test_audio(n_samples, seed=11)
+    codes, lens = dac.encode(audio)
+    ref_codes = g[f"{tag}.codes"]
+    assert codes.shape == ref_codes.shape and int(lens[0]) == ref_codes.shape[-1]
+    same = (codes.cpu() == ref_codes)
+    frac = float(same.float().mean())
+    assert frac >= min_code_match, frac
+    ok = same.all(dim=1)[0]                                   # frames with every code equal
+    zq = dac.encode_zq(audio).cpu()
+    ref_zq = g[f"{tag}.zq"]
+    e = float((zq[0][:, ok] - ref_zq[0][:, ok]).pow(2).mean().sqrt())
+    assert e < 1e-5 * max(1.0, U.rms(ref_zq)), (e, U.rms(ref_zq))
+    pca = R.make_pca(cfg, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    lat = E.ae_encode(dac, st, audio).cpu()
+    ref_lat = g[f"{tag}.ae_encode"]
+    e2 = float((lat[0][ok] - ref_lat[0][ok]).pow(2).mean().sqrt())
+    assert e2 < 1e-5 * max(1.0, U.rms(ref_lat)), e2
+    return dac, st, audio, frac
+
+
+def test_dac_encode_tiny_matches_reference(golden):
+    from tests.golden_defs import TINY_ENC_SAMPLES
+    dac, st, audio, frac = _check_encode(golden, "enc_tiny", TINY_DAC, TINY_ENC_SAMPLES, 0.95)
+    lat, mask = E.get_speaker_latent_and_mask(dac, st, audio[0].to(DEV), max_speaker_latent_length=24, audio_chunk_size=4 * 2048)
+    assert lat.shape == golden["enc_tiny.spk_latent"].shape and torch.equal(mask.cpu().to(torch.uint8), golden["enc_tiny.spk_mask"])
+    if frac == 1.0:
+        assert rms(lat, golden["enc_tiny.spk_latent"]) < 1e-5 * max(1.0, U.rms(golden["enc_tiny.spk_latent"]))
+
+
+def test_dac_encode_full_size_matches_reference(golden):
+    """Full-size encoder: 4-layer window-512 transformer over 600 positions, pre_module, VQ 4096 + 9 x 1024."""
+    from tests.golden_defs import FULL_ENC_SAMPLES
+    _check_encode(golden, "enc_full", R.DacConfig(), FULL_ENC_SAMPLES, 0.97)
+
+
+def test_dac_encode_is_causal(golden):
+    """Size-independent property: the encoder is causal, so the codes of a longer signal start with those of its prefix
+    (whole frames), and a round trip decode(encode(x)) has the length of the padded input."""
+    cfg = TINY_DAC
+    dac = E.DAC(cfg, _enc_weights(cfg), device=DEV)
+    audio = R.make_test_audio(2048 * 12, seed=5)
+    ca, _ = dac.encode(audio[..., : 2048 * 7])
+    cb, _ = dac.encode(audio)
+    assert torch.equal(ca, cb[..., :7])
+    wav = dac.decode_zq(dac.encode_zq(audio))
+    assert wav.shape == (1, 1, 2048 * 12) and bool(torch.isfinite(wav).all())
+
+
 def test_dac_is_causal_and_length_independent(golden):
     """Size-independent property: decoding a longer input reproduces the shorter one's samples."""
     cfg = TINY_DAC
