@@ -1076,6 +1076,7 @@ typedef TileCfg<128, 256, 2, 4, 3> Cfg4;   // 8 waves (64x64 each), 144 KiB, 2 t
 template <typename T, bool SW>
 hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
   if constexpr (!Num<T>::is_bf16) {
+    if (g.cfg >= 5) return hipErrorInvalidValue;   // the ping-pong kernel (and its diagnostic builds) is bf16 only
     if (g.split3) {
       switch (g.cfg) {
         case 1: return launch_cfg<T, SW, Cfg1, true>(g, st);

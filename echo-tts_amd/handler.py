@@ -85,10 +85,16 @@ def normalize_chunk_boundaries(audio_chunks: List[torch.Tensor], sample_rate: in
 
 
 def synthesize(job_input: Dict, model, fish_ae, pca_state, speaker_latent: Optional[torch.Tensor] = None,
-               speaker_mask: Optional[torch.Tensor] = None) -> Dict:
+               speaker_mask: Optional[torch.Tensor] = None, speaker_audio: Optional[torch.Tensor] = None) -> Dict:
     """The compute part of the reference `_synthesize` (handler.py:682-803): validate, chunk, one sample_pipeline per
-    chunk with seed + 1000*idx, normalise boundaries / cross-fade, return audio + metadata (or an error dict)."""
+    chunk with seed + 1000*idx, normalise boundaries / cross-fade, return audio + metadata (or an error dict).
+    `speaker_audio` (1, length) at 44.1 kHz is encoded ONCE per request on the GPU (the reference re-encodes the voice for
+    every text chunk, handler.py:750-758); `speaker_latent` / `speaker_mask` pass an already encoded (cached) voice."""
     try:
+        if speaker_latent is None and speaker_audio is not None:
+            from .inference import get_speaker_latent_and_mask
+            speaker_latent, speaker_mask = get_speaker_latent_and_mask(fish_ae, pca_state, speaker_audio.to(model.device))
+            speaker_latent = speaker_latent.to(model.dtype)
         text = job_input.get("text")
         if not text or not str(text).strip():
             raise ValueError("text is required")
