@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       // vmcnt wait into __syncthreads() here (it only tracked the prologue's DMAs): without this explicit wait the
       // kernel was non-deterministic at full size (caught by tests/test_gpu_kernels.py::test_attention_is_deterministic).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (PROF) { const unsigned long long tv = stamp(); pt[4] += tv - t0; }
       __syncthreads();   // K(t+1), V(t) landed; every wave finished QK(t) and PV(t-1)
       if (PROF) t1 = stamp();
       // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the cursors stay on the last
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the rings are reused / the workgroup ends
   if (PROF && lane == 0) {
     unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wid) * 8;
-    dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3];
+    dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4];
   }
 
   // ---- merge the two key halves of each query block: waves kh = 1 park (O, m, l) in LDS, waves kh = 0 combine
