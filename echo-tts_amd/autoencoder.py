@@ -132,10 +132,13 @@ class DAC:
         torch.cuda.set_device(self._device)
         self._load(state_dict)
         pm = "quantizer.post_module.freqs_cis"
-        if pm in state_dict:  # persistent buffer wins (autoencoder.py:562-569)
+        # one table serves post_module / pre_module (block_size 4096) and the encoder transformer (block_size 16384,
+        # autoencoder.py:1163-1165): same head_dim and base, so the shorter caches are prefixes of the longer one
+        npos = max(c.post_block_size, 16384 if self._has_encoder else 0)
+        if pm in state_dict and state_dict[pm].shape[0] >= npos:  # persistent buffer wins (autoencoder.py:562-569)
             cache = state_dict[pm].float().contiguous()
         else:
-            cache = ae_rope_cache(c.post_block_size, c.post_head_dim, c.rope_base)
+            cache = ae_rope_cache(npos, c.post_head_dim, c.rope_base)
         self._rope = cache.to(self._device)
         L.check(self._lib.echo_set_ae_rope_table(self._ctx, self._rope.data_ptr(), self._rope.shape[0]), self._ctx)
         self._pca_key = None

@@ -326,6 +326,42 @@ def test_pipeline_and_handler_surface(golden, tiny_models, dname, dt):
     assert out["chunks"] == len(H.chunk_text_for_audio(long_text, 300, 2.5)) and out["audio"].shape[-1] > 0
 
 
+def test_voice_cloning_pipeline_from_audio(golden, tiny_models):
+    """The whole reference flow of handler.py:750-758 on the tiny models, starting from speaker AUDIO: DAC encode ->
+    get_speaker_latent_and_mask -> sampler -> ae_decode -> crop, against the oracle run stage by stage on the same inputs."""
+    from functools import partial
+    from echo_tts_amd import handler as H
+    from echo_tts_amd import inference as inf
+    m = tiny_models["f32"]
+    dw = R.make_dac_weights(TINY_DAC, 0)
+    dw.update(R.make_dac_encoder_weights(TINY_DAC, 0))
+    dac = E.DAC(TINY_DAC, dw, device=DEV)
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    voice = R.make_test_audio(2048 * 16 + 700, seed=21)[0]               # (1, n): 16 whole frames + a partial one
+    fn = partial(E.sample_euler_cfg_independent_guidances, sequence_length=32, **SAMPLER_CASES["cfg_default"])
+    audio, norm = E.sample_pipeline(m, dac, st, fn, "Hello world.", voice, 3, pad_to_max_text_length=64)
+    assert norm == "[S1] Hello world." and bool(torch.isfinite(audio).all())
+    # oracle, same stages (the 30 s zero-padded chunk gives 640 pre_module positions: more than the tiny block_size, so the
+    # oracle's rope cache is built longer; its values do not depend on the cache length)
+    import dataclasses
+    spk, smask = R.get_speaker_latent_and_mask(dw, dataclasses.replace(TINY_DAC, post_block_size=4096), pca, voice)
+    assert spk.shape == (1, 16, 80)
+    got_spk, got_mask = E.get_speaker_latent_and_mask(dac, st, voice.to(DEV))
+    assert torch.equal(got_mask.cpu(), smask) and rms(got_spk, spk) < 1e-5 * max(1.0, U.rms(spk))
+    ids, tmask = inf.get_text_input_ids_and_mask(["Hello world."], max_length=64)
+    x0 = torch.randn((1, 32, 80), device=DEV, dtype=torch.float32, generator=torch.Generator(device=DEV).manual_seed(3)).cpu()
+    w = R.make_dit_weights(TINY, seed=0)
+    lat = R.sample_euler(w, TINY, torch.float32, spk, smask, ids, tmask, rng_seed=3, sequence_length=32, x_init=x0,
+                         **SAMPLER_CASES["cfg_default"])
+    wav = R.ae_decode(dw, TINY_DAC, pca, lat)
+    wav = wav[..., : R.find_flattening_point(lat[0]) * 2048]
+    assert wav.shape == audio.shape and rms(audio, wav) < WAV_TOL
+    out = H.synthesize({"text": "Hello world. Again.", "parameters": {"num_steps": 4, "sequence_length": 32}}, m, dac, st,
+                       speaker_audio=voice)
+    assert "error" not in out, out.get("traceback")
+
+
 @pytest.mark.parametrize("case,opts,cont", [("plain", "cfg_default", False), ("cont_opts", "all_options", True)])
 def test_blockwise_sampler_bf16_within_reference_noise(golden, tiny_models, case, opts, cont):
     g, m = golden, tiny_models["bf16"]
