@@ -239,7 +239,11 @@ def main() -> None:
         E.ae_decode(dac, pca, lat)
         dp = dac.get_profile()
         dac.set_profiling(False)
-        phases = {"utterances_per_call": nb, "sampler_ms": round(pr.ms_total, 2), "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
+        # joint attention inside the sampler call: algorithmic FLOPs of SURVEY.md 8d (14.57 TFLOP per utterance at C2)
+        attn_flops = nb * 640 * 196608.0 * 115760.0
+        attn = {"ms": round(pr.ms_attn_sum, 2), "launches": pr.n_attn,
+                "achieved_tflops": round(attn_flops / (pr.ms_attn_sum * 1e-3) / 1e12, 1) if pr.n_attn else None}
+        phases = {"utterances_per_call": nb, "sampler_ms": round(pr.ms_total, 2), "attention": attn, "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
                   "dac_decode_ms_per_utterance": round(dp.ms_total, 2), "dac_gemm_ms_per_utterance": round(dp.ms_gemm_sum, 2)}
     single = None
     if rank == 0 and nb * conc > 1 and not args.no_roofline:

@@ -86,7 +86,8 @@ class EchoAttnDesc(C.Structure):
 
 class EchoProfile(C.Structure):
     _fields_ = [("ms_mod", C.c_float), ("ms_steps", C.c_float), ("ms_total", C.c_float), ("ms_gemm_sum", C.c_float),
-                ("n_gemm", C.c_int), ("ms_pp_sum", C.c_float), ("n_pp", C.c_int), ("flops_pp", C.c_double)]
+                ("n_gemm", C.c_int), ("ms_pp_sum", C.c_float), ("n_pp", C.c_int), ("flops_pp", C.c_double),
+                ("ms_attn_sum", C.c_float), ("n_attn", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/echo_hip.h declares

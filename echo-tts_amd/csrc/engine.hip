@@ -16,6 +16,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
+struct Plan { int cfg = 0, ksplit = 1; };
+std::map<int, std::map<std::vector<long>, Plan>> g_plans;   // device -> (shape key -> plan); engines are used from one thread
+
 inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 
 struct DevBuf {
@@ -90,11 +93,14 @@ struct EngineBase {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
   std::vector<double> gemm_event_flops;   // > 0: a gemm_pp_kernel launch (plan cfg 5) with that many algorithmic FLOPs
   size_t gemm_events_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> attn_events;
+  size_t attn_events_used = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   virtual ~EngineBase() {
     for (auto& kv : raw) if (kv.second.d) (void)hipFree(kv.second.d);
     for (auto& e : gemm_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : attn_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
   }
   int fail(const std::string& m) { err = m; return ECHO_ERR; }
@@ -216,8 +222,10 @@ struct Engine : EngineBase {
     return g;
   }
   // ------------------------------------------------------------------ GEMM plans (tile config + split-K per shape)
-  struct Plan { int cfg = 0, ksplit = 1; };
-  std::map<std::vector<long>, Plan> plans;
+  // plans are shared by every context of the process on the same device (a second engine context of a serving process
+  // must not re-tune while the first one is already running kernels: its timings would be garbage)
+  std::map<std::vector<long>, Plan>& plans = g_plans[device_key()];
+  int device_key() { int d = 0; (void)hipGetDevice(&d); return d; }
   DevBuf b_gemm_ws, b_tune_c, b_flush;
   bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : true;
 
@@ -474,6 +482,18 @@ struct Engine : EngineBase {
       }
       a.nseg = n;
       if (n == 0) return fail("attention without keys");
+      if (profiling) {
+        if (attn_events_used == attn_events.size()) {
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+          attn_events.emplace_back(e0, e1);
+        }
+        auto& e = attn_events[attn_events_used++];
+        CK(hipEventRecord(e.first, st));
+        CK(launch_attention_bf16(a, st));
+        CK(hipEventRecord(e.second, st));
+        return ECHO_OK;
+      }
       CK(launch_attention_bf16(a, st));
       return ECHO_OK;
     } else {
@@ -932,7 +952,7 @@ struct Engine : EngineBase {
     float* xs = b_xstate.as<float>();
     if (profiling) {
       for (auto& e : ev) if (!e) CK(hipEventCreate(&e));
-      gemm_events_used = 0;
+      gemm_events_used = 0; attn_events_used = 0;
       CK(hipEventRecord(ev[0], st));
     }
     CK(hipMemcpyAsync(xs, x0, (size_t)B * S * Lz * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -977,6 +997,11 @@ struct Engine : EngineBase {
   }
   void collect_gemm_times() {
     prof.ms_gemm_sum = 0.f; prof.n_gemm = 0; prof.ms_pp_sum = 0.f; prof.n_pp = 0; prof.flops_pp = 0.0;
+    prof.ms_attn_sum = 0.f; prof.n_attn = 0;
+    for (size_t i = 0; i < attn_events_used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, attn_events[i].first, attn_events[i].second) == hipSuccess) { prof.ms_attn_sum += ms; ++prof.n_attn; }
+    }
     for (size_t i = 0; i < gemm_events_used; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) == hipSuccess) {

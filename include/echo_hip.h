@@ -190,6 +190,7 @@ typedef struct {
      stream and their algorithmic FLOPs 2 * M * N * K * taps (bench.py "roofline") */
   float ms_pp_sum; int n_pp;
   double flops_pp;
+  float ms_attn_sum; int n_attn;   /* attn_kernel launches of that run (HIP events on the launch stream) */
 } echo_profile;
 int echo_set_profiling(echo_ctx* ctx, int on);
 int echo_get_profile(echo_ctx* ctx, echo_profile* out);
