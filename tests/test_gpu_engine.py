@@ -326,6 +326,35 @@ def test_pipeline_and_handler_surface(golden, tiny_models, dname, dt):
     assert out["chunks"] == len(H.chunk_text_for_audio(long_text, 300, 2.5)) and out["audio"].shape[-1] > 0
 
 
+@pytest.mark.parametrize("dname,dt,tol", [("f32", torch.float32, 2e-5), ("bf16", torch.bfloat16, 8e-2)])
+def test_batched_call_equals_single_calls_at_full_width(dname, dt, tol):
+    """BASELINE config C3's shape of work at real widths (d = 2048 x 16 heads, encoders 1280 x 10, one layer each): four
+    utterances with different text lengths and speaker lengths through ONE sampler call (the reference's batch axis, which
+    is what bench.py times) must give what four single-utterance calls give.  fp32: same arithmetic up to the GEMM plan
+    (tile / split-K choice changes the summation order); bf16: two different sets of bf16 rounding points (other tiles, other
+    split-K) amplified by CFG scale 8 on random weights, so only a sanity bound (measured 3e-2)."""
+    from echo_tts_amd.inference import get_text_input_ids_and_mask
+    cfg = WIDE1
+    w = R.make_dit_weights(cfg, seed=0)
+    m = E.EchoDiT(cfg, {k: v.to(dt) for k, v in w.items()}, dtype=dt, device=DEV)
+    texts = ["[S1] Hello world.", "[S1] A somewhat longer sentence, with a clause in the middle.", "[S1] Short.",
+             "[S1] The quick brown fox jumps over the lazy dog near the river bank at dawn."]
+    ids, tmask = get_text_input_ids_and_mask(texts, max_length=96)
+    g = torch.Generator().manual_seed(9)
+    spk = torch.randn((4, 64, 80), generator=g)
+    smask = torch.ones((4, 64), dtype=torch.bool)
+    smask[1, 48:] = False
+    smask[3, 32:] = False
+    x0 = torch.randn((4, 64, 80), generator=g)
+    kw = dict(SAMPLER_CASES["cfg_default"], num_steps=4)
+    both = E.sample_euler_cfg_independent_guidances(m, spk, smask, ids, tmask, rng_seed=0, sequence_length=64, x_init=x0, **kw).cpu()
+    for b in range(4):
+        one = E.sample_euler_cfg_independent_guidances(m, spk[b:b + 1], smask[b:b + 1], ids[b:b + 1], tmask[b:b + 1], rng_seed=0,
+                                                       sequence_length=64, x_init=x0[b:b + 1], **kw).cpu()
+        e = rms(both[b:b + 1], one)
+        assert e < tol * max(1.0, U.rms(one)), (b, e, U.rms(one))
+
+
 def test_voice_cloning_pipeline_from_audio(golden, tiny_models):
     """The whole reference flow of handler.py:750-758 on the tiny models, starting from speaker AUDIO: DAC encode ->
     get_speaker_latent_and_mask -> sampler -> ae_decode -> crop, against the oracle run stage by stage on the same inputs."""
