@@ -119,6 +119,24 @@ def test_euler_sampler_bf16_with_forced_gemm_plans(golden, monkeypatch, force):
     assert e < _bf16_budget(g, f"{tag}.bf16.euler.{case}", f"{tag}.f32.euler.{case}"), e
 
 
+@pytest.mark.parametrize("force", ["5,1", None])
+def test_ragged_sequence_length_bf16(golden, monkeypatch, force):
+    """sequence_length 20 (not a multiple of 8, not of 16): the transposed-V stores of the fused QKV epilogue take their
+    element-wise tail path and the last 128-query attention block is ragged.  bf16 engine (ping-pong GEMM forced / plans
+    as tuned) against the fp32 oracle on the same inputs, within the bf16 budget of the tiny model."""
+    if force:
+        monkeypatch.setenv("ECHO_GEMM_FORCE", force)
+    w = R.make_dit_weights(TINY, seed=0)
+    m = E.EchoDiT(TINY, {k: v.bfloat16() for k, v in w.items()}, dtype=torch.bfloat16, device=DEV)
+    g, tag = golden, "tinyb2"
+    x0 = g[f"{tag}.x0"][:, :20].contiguous()
+    args = (g[f"{tag}.spk"], g[f"{tag}.smask"].bool(), g[f"{tag}.ids"], g[f"{tag}.tmask"].bool())
+    lat = E.sample_euler_cfg_independent_guidances(m, *args, rng_seed=0, sequence_length=20, x_init=x0, **SAMPLER_CASES["cfg_default"])
+    ref = R.sample_euler(w, TINY, torch.float32, *args, rng_seed=0, sequence_length=20, x_init=x0, **SAMPLER_CASES["cfg_default"])
+    budget = _bf16_budget(g, f"{tag}.bf16.euler.cfg_default", f"{tag}.f32.euler.cfg_default")
+    assert rms(lat, ref) < 1.5 * budget, (rms(lat, ref), budget)
+
+
 @pytest.mark.parametrize("case,opts,cont", [("plain", "cfg_default", False), ("cont_opts", "all_options", True)])
 def test_blockwise_sampler_f32(golden, tiny_models, case, opts, cont):
     g, m = golden, tiny_models["f32"]
