@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
 //        phase r - 1 (at most 2 (LEAD - 2) younger DMAs stay in flight), then passes the barrier that ends that
 //        part; both groups have done so before either reads (G0 reads two barriers, G1 one barrier later);
 //   WAR  unit u overwrites unit u - 8, last read in phase u - 8 - {0,1,1,1}[j]; those reads are retired by the
-//        lgkmcnt(0) at the head of that phase's MFMA part, so restaging two phases later is safe: LEAD <= 6.
+//        lgkmcnt(0) in front of that phase's first barrier, so restaging two phases later is safe: LEAD <= 6.
 // Never vmcnt(0) in the loop: the look-ahead units of the last phases re-stage the final K-tile into dead ring slots.
 //
 // The kernel is PERSISTENT: gridDim.x workgroups (one per CU) walk the tile list with stride gridDim.x, and the unit
@@ -567,7 +567,7 @@ __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, flo
 // DIAG (timing experiments only): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 4 = no epilogue
 // (1-4 give wrong results); 5 = correct results + per-wave cycle sums (s_memtime) written to p.ws: {total, K loops,
 // epilogue, tiles} x 8 waves per workgroup; 6 = correct results + per-wave, per-phase cycle sums {load part, wait at
-// barrier 1, MFMA part, wait at barrier 2} x 4 phases
+// barrier 1, MFMA part, wait at barrier 2} x 4 phases; 7 = the epilogue without its global stores (wrong results)
 template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   typedef bf16_t T;
@@ -735,11 +735,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     // ---- the units first read in the next phase have landed (this wave's part of them)
     if constexpr (q != 2) wait_vmcnt<2 * (LEAD - 2)>();
     if constexpr (DIAG == 6) s1 = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();
+    // the fragments are retired BEFORE the barrier (the wave would only wait at the barrier anyway; measured +3-4 % over
+    // waiting behind it), and no s_setprio flips around the MFMA cluster (measured +3 %: the partner wave is in its load
+    // part and barely competes for the vector issue port; the sched_barriers keep the cluster between the two barriers)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if constexpr (DIAG == 6) s2 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
     if constexpr (DIAG == 3) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[i][0]), "v"(af[i][1]));
@@ -754,7 +756,6 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         for (int jn = 0; jn < 4; ++jn)
           acc[2 * mh + i][4 * nh + jn] =
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][jn][kk], af[i][kk], acc[2 * mh + i][4 * nh + jn], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DIAG == 6) s3 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
@@ -938,6 +939,59 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           }
         }
       }
+    } else if (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7) {
+      // fast path of the big EchoDiT linears: y = T(acc) [* colscale] [+ residual].  Fully unrolled (static accumulator
+      // reads), addresses hoisted: one 64-bit per-lane offset per tile, everything else wave-uniform; the residual rows of
+      // a piece are requested before its LDS round trip; interior tiles skip the per-element bounds tests.
+      const int row0 = lane >> 3, c8 = lane & 7;
+      const bool full = m_base + 64 <= p.M && n_base + 128 <= p.N;          // wave-uniform
+      const long off0 = (long)(m_base + row0) * p.ldc + n_base + 8 * c8;
+      const long roff0 = (long)(m_base + row0) * p.ldres + n_base + 8 * c8;
+      const T* const resp = p.res ? (const T*)p.res + zo * p.res_bo + zi * p.res_bi : nullptr;
+      float cs[2][8];
+      if (p.colscale) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int n0 = n_base + 64 * h + 8 * c8;
+          unpack8_bf16(n0 < p.N ? *(const uint4*)((const T*)p.colscale + n0) : uint4{0, 0, 0, 0}, cs[h]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint4 rr[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+          if (resp) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
+              if (full || (m < p.M && n0 < p.N)) rr[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr * 16 + ((c * 4 + fg) ^ fr)) * 4) = acc[i][4 * h + c];
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + row0;
+            const f32x4 a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
+            const f32x4 b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+            float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e]);
+            if (p.colscale) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] * cs[h][e]);
+            }
+            if (resp) {
+              float r[8];
+              unpack8_bf16(rr[it], r);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] + r[e]);
+            }
+            const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+            if (full || (m < p.M && n0 < p.N)) *(uint4*)(C + off0 + (long)(16 * i + 8 * it) * p.ldc + 64 * h) = pack8_bf16(y);
+          }
+        }
     } else {
       // the tail is emitted once (runtime loop over the 8 pieces); the accumulators of piece 2 i + h are picked by
       // static register reads pinned with an empty asm (merged stores would turn `acc` into a scratch array)
@@ -955,7 +1009,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         const int i_ = piece >> 1, h_ = piece & 1;
         rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
           const int m = m_base + 16 * i_ + row, n0 = n_base + 64 * h_ + 8 * c8;
-          if (m < p.M && n0 < p.N) gemm_tail8(p, m, n0, y, zo, zi, C);
+          if constexpr (DIAG == 7) {          // timing experiment: the whole epilogue but the global stores
+            asm volatile("" :: "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+          } else {
+            if (m < p.M && n0 < p.N) gemm_tail8(p, m, n0, y, zo, zi, C);
+          }
         });
       }
     }
@@ -1106,6 +1164,7 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
       if (g.cfg == 104) return launch_pp<false, 4>(g, st);
       if (g.cfg == 105) return launch_pp<false, 5>(g, st);
       if (g.cfg == 108) return launch_pp<false, 6>(g, st);
+      if (g.cfg == 109) return launch_pp<false, 7>(g, st);
       if (g.cfg == 106) return launch_pp<false, 0, 6>(g, st);
       if (g.cfg == 107) return launch_pp<false, 0, 4>(g, st);
     }
@@ -1130,7 +1189,7 @@ hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   constexpr int KE = KBYTES / (int)sizeof(T);
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 108)))
+      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 109)))
     return hipErrorInvalidValue;
   if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
     return hipErrorInvalidValue;
