@@ -1,18 +1,19 @@
-// gemm_nt: C = epilogue(A · Wᵀ) on MFMA, bf16 (v_mfma_f32_32x32x16_bf16) or exact fp32
-// (v_mfma_f32_32x32x2_f32).  One kernel serves every Linear on the hot path (reference: every
-// nn.Linear in model.py / autoencoder.py) and, through the `taps` loop, every causal Conv1d /
-// ConvTranspose1d of the DAC decoder in channels-last layout (autoencoder.py:264-331).
+// GEMM kernels of libechohip: C = epilogue(A · Wᵀ), both operands K-contiguous.
 //
-// Tile configurations (TileCfg): 128x128 / 256x128 / 128x256 / 256x256 output tiles, 4 or 8 waves, 2-4 LDS
-// stages with a counted-vmcnt DMA pipeline; K-step = 128 bytes per row (64 bf16 / 32 fp32); optional split-K
-// with fp32 partial slabs and a deterministic reduce + tail kernel.
-// Both operands are K-contiguous, so A and W tiles are staged the same way: direct global->LDS
-// DMA (global_load_lds_dwordx4), lane-linear LDS image, XOR swizzle applied on the SOURCE address
-// (chunk ^= (row>>1)&7) and again on the ds_read_b128 address, which makes every fragment read
-// conflict-free (cdna_hip_programming.md §5.4 rule 21, §5.5 T2).  Double-buffered, one barrier per
-// K-step.  Operands are swapped into the MFMA (W rows -> MFMA rows, activation rows -> MFMA
-// columns) so that each lane ends up with 4 consecutive output columns of one output row: the
-// epilogue stores 8 B (bf16) / 16 B (fp32) vectors and the SwiGLU pair (w1, w3) lives in one lane.
+// * gemm_pp_kernel (plan cfg 5): bf16, persistent 256x256 "ping-pong" kernel on v_mfma_f32_16x16x32_bf16 — every large
+//   EchoDiT linear (QKVG with its fused head-norm / RoPE / Vᵀ tail, wo, SwiGLU w1‖w3, w2).  Described at its definition.
+// * gemm_nt_kernel (plans 0-4): bf16 (v_mfma_f32_32x32x16_bf16), exact fp32 (v_mfma_f32_32x32x2_f32) and fp32 "split3"
+//   (three bf16 MFMAs per product).  One kernel serves the small / odd-shaped linears (reference: every nn.Linear in
+//   model.py / autoencoder.py) and, through the `taps` loop, every causal Conv1d / ConvTranspose1d of the DAC in
+//   channels-last layout (autoencoder.py:264-331).  Tile configurations (TileCfg): 128x128 / 256x128 / 128x256 / 256x256
+//   output tiles, 4 or 8 waves, 2-4 LDS stages with a counted-vmcnt DMA pipeline; K-step = 128 bytes per row (64 bf16 /
+//   32 fp32); optional split-K with fp32 partial slabs and a deterministic reduce + tail kernel.
+//
+// Common to both: A and W tiles are staged by direct global->LDS DMA (global_load_lds_dwordx4) into a lane-linear LDS
+// image; the XOR swizzle is applied on the SOURCE address (chunk ^= (row>>1)&7) and again on the ds_read_b128 address,
+// which makes every fragment read conflict-free (cdna_hip_programming.md §5.4 rule 21, §5.5 T2).  Operands are swapped
+// into the MFMA (W rows -> MFMA rows, activation rows -> MFMA columns) so that each lane ends up with 4 consecutive
+// output columns of one output row: the SwiGLU pair (w1, w3) and the RoPE pairs live in one lane.
 #include "common.h"
 #include <cstdlib>
 
