@@ -166,3 +166,23 @@ def random_dac_state(cfg: DACConfig, device, seed: int = 0) -> Dict[str, torch.T
             v = sd[name.replace("original0", "original1")]
             sd[name] = 0.5 * v.flatten(1).norm(dim=1).view(-1, 1, 1)
     return sd
+
+
+def fake_quant_fp8_e4m3(w: torch.Tensor) -> torch.Tensor:
+    """Weight-only fp8 storage numerics (BASELINE config C5): per-output-row scale to the OCP e4m3 range (max 448), round to
+    `torch.float8_e4m3fn`, scale back.  The result is what an fp8 weight path multiplies with; this repo has no fp8 MFMA kernel
+    yet, so the dequantised matrix runs on the bf16 kernels (same numerics as dequantise-on-load, no speed-up)."""
+    wf = w.detach().float()
+    s = wf.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) / 448.0
+    q = (wf / s).to(torch.float8_e4m3fn).float() * s
+    return q.to(w.dtype)
+
+
+def fp8_weight_state(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """EchoDiT state dict with every transformer-block linear of the DiT (attention, MLP, the conditioning keys' projections)
+    passed through fake_quant_fp8_e4m3; norms, embeddings, AdaLN low-rank factors and biases stay as they are."""
+    out = {}
+    for k, v in sd.items():
+        lin = v.dim() == 2 and k.startswith("blocks.") and (".attention.w" in k or ".attention.gate" in k or ".mlp.w" in k)
+        out[k] = fake_quant_fp8_e4m3(v) if lin else v
+    return out

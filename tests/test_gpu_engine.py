@@ -373,6 +373,22 @@ def test_batched_call_equals_single_calls_at_full_width(dname, dt, tol):
         assert e < tol * max(1.0, U.rms(one)), (b, e, U.rms(one))
 
 
+def test_fp8_weight_numerics_c5(golden, tiny_models):
+    """BASELINE config C5 as a parity case: DiT block linears stored as OCP fp8-e4m3 (per-row scale), 100 Euler steps.  No
+    tolerance is promised for fp8: the RMS distance to the bf16 engine is reported and only sanity-bounded."""
+    from echo_tts_amd.weights import fp8_weight_state
+    g, tag = golden, "tiny"
+    w = {k: v.bfloat16() for k, v in R.make_dit_weights(TINY, seed=0).items()}
+    m8 = E.EchoDiT(TINY, fp8_weight_state(w), dtype=torch.bfloat16, device=DEV)
+    kw = dict(SAMPLER_CASES["cfg_default"], num_steps=100)
+    args = (g[f"{tag}.spk"], g[f"{tag}.smask"].bool(), g[f"{tag}.ids"], g[f"{tag}.tmask"].bool())
+    a = E.sample_euler_cfg_independent_guidances(tiny_models["bf16"], *args, rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"], **kw)
+    b = E.sample_euler_cfg_independent_guidances(m8, *args, rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"], **kw)
+    e = rms(a, b)
+    print(f"C5 (tiny, 100 steps): fp8-e4m3 weights vs bf16 weights: latent rms distance {e:.3e} (latent rms {U.rms(a):.3f})")
+    assert bool(torch.isfinite(b).all()) and 0.0 < e < 0.5 * U.rms(a)
+
+
 def test_voice_cloning_pipeline_from_audio(golden, tiny_models):
     """The whole reference flow of handler.py:750-758 on the tiny models, starting from speaker AUDIO: DAC encode ->
     get_speaker_latent_and_mask -> sampler -> ae_decode -> crop, against the oracle run stage by stage on the same inputs."""
