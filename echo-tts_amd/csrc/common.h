@@ -102,6 +102,7 @@ struct GemmArgs {
   int ksplit;                   // > 1: split K over blockIdx.z, fp32 partial slabs in ws, reduce kernel applies the tail
   void* ws; long ws_bytes;
   int split3;                   // fp32 only: bf16 hi/lo operand splitting, 3 bf16 MFMAs per product (gemm.hip SPLIT3)
+  int pp_gn;                    // gemm_pp_kernel: tile columns per strip of the tile order (0 = default PP_GN)
   // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the
   // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
   // position pos0 + (m % qkv_S); the v section is written TRANSPOSED to vt[(m / S)][h][d][m % S]; gate is stored as is.

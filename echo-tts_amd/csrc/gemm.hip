@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   auto tile_of = [&](int v, int& tm, int& tn) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
     const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GN = PP_GN;
+    const int GN = p.pp_gn > 0 ? p.pp_gn : PP_GN;
     const int strip = b / (GN * tiles_m), rem = b - strip * (GN * tiles_m);
     const int w = tiles_n - strip * GN < GN ? tiles_n - strip * GN : GN;
     tm = rem / w; tn = strip * GN + (rem - tm * w);
@@ -1103,7 +1103,10 @@ int pp_num_cus() {
 }
 
 template <bool SW, int DIAG = 0, int LEAD = PP_LEAD>
-hipError_t launch_pp(const GemmArgs& g, hipStream_t st) {
+hipError_t launch_pp(const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  static const int env_gn = getenv("ECHO_PP_GN") ? atoi(getenv("ECHO_PP_GN")) : 0;
+  if (g.pp_gn <= 0 && env_gn > 0) g.pp_gn = env_gn;
   static bool attr_set = false;
   auto kern = gemm_pp_kernel<SW, DIAG, LEAD>;
   constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
