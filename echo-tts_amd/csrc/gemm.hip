@@ -785,8 +785,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   };
 
   int tcount = 0;
-  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, n_tiles = 0;
-  if constexpr (DIAG == 5) t_start = __builtin_amdgcn_s_memtime();
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, n_tiles = 0, rt_start = 0;
+  if constexpr (DIAG == 5) { t_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
   for (int v = blockIdx.x; v < ntiles; v += G) {
     int tile_m, tile_n;
@@ -1032,7 +1032,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   if constexpr (DIAG == 5) {
     if (lane == 0 && p.ws) {
       unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 8;
-      o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_loop; o[2] = t_epi; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = n_tiles; o[7] = 0;
+      o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_loop; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memrealtime() - rt_start;   // o[3]: 100 MHz ticks
+      o[4] = 0; o[5] = 0; o[6] = n_tiles; o[7] = 0;
     }
   }
   wait_vmcnt<0>();   // the re-staged look-ahead units must not land after the workgroup has released its LDS

@@ -10,7 +10,7 @@ for (M, N, K) in ((7680, 8192, 2048), (7680, 2048, 5888), (2560, 8192, 2048)):
     C = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
     ws = torch.zeros((256 * 8 * 8,), dtype=torch.int64, device="cuda")
     kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, Npad=(N + 127) // 128 * 128)
-    for _ in range(3):
+    for _ in range(40):     # long enough for the clock to settle under load
         U.gemm(A, W, C, cfg=105, ws=ws, **kw)
     torch.cuda.synchronize()
     r = ws.view(256, 8, 8).double()
@@ -22,7 +22,8 @@ for (M, N, K) in ((7680, 8192, 2048), (7680, 2048, 5888), (2560, 8192, 2048)):
         line = f"M={M} N={N} K={K} {grp}: tiles/wg {tiles:.2f} |"
         for i, n in enumerate(names):
             line += f" {n} {x[:, i].mean().item() / tiles:9.0f}"
-        print(line + "  (cycles per tile, s_memtime ticks)", flush=True)
+        clk = (x[:, 0] / (x[:, 3] / 100e6)).mean().item() / 1e9
+        print(line + f"  (cycles per tile, s_memtime ticks); in-kernel clock {clk:.2f} GHz (s_memtime / s_memrealtime)", flush=True)
 
 # per-phase breakdown (cfg 108)
 M, N, K = 7680, 8192, 2048
