@@ -262,6 +262,22 @@ def test_dac_encode_is_causal(golden):
     assert wav.shape == (1, 1, 2048 * 12) and bool(torch.isfinite(wav).all())
 
 
+def test_dac_full_size_160_frames_against_oracle():
+    """Full-size Fish S1-DAC decode of 160 latent frames (327 680 samples, a quarter of config C2's 640) against the CPU
+    oracle on the same seeded weights: waveform within the north-star 1e-4 RMS (the 8-frame reference fixture does not
+    exercise the window-128 attention mask or the large-M convolution tiles)."""
+    cfg = R.DacConfig()
+    w = R.make_dac_weights(cfg, 0)
+    z = torch.randn((1, cfg.latent_dim, 160), generator=torch.Generator().manual_seed(7))
+    torch.set_num_threads(16)
+    want = R.dac_decode_zq(w, cfg, z)
+    dac = E.DAC(cfg, w, device=DEV)
+    got = dac.decode_zq(z)
+    e = rms(got, want)
+    print(f"DAC full size, 160 frames: waveform rms error {e:.3e} (signal rms {U.rms(want):.3e})")
+    assert got.shape == want.shape and e < WAV_TOL and e < 1e-3 * U.rms(want), (e, U.rms(want))
+
+
 def test_dac_is_causal_and_length_independent(golden):
     """Size-independent property: decoding a longer input reproduces the shorter one's samples."""
     cfg = TINY_DAC
@@ -304,6 +320,32 @@ def test_c1_full_depth_fp32_against_oracle():
     print(f"C1 full depth: fp32 engine rms {e:.3e}; bf16 engine rms {eb:.3e} vs fp32 oracle; PyTorch bf16 vs fp32 {eref:.3e}; "
           f"bf16 engine vs PyTorch bf16 {rms(gotb, wantb):.3e} (latent rms {U.rms(want):.3f})")
     assert eb < 1.5 * eref + 1e-3, (eb, eref)
+
+
+def test_c2_shape_full_depth_cfg_fp32_against_oracle():
+    """BASELINE config C2's SHAPES at full size with CFG on: 24-layer EchoDiT, S = 640, text of 436 tokens padded to 768,
+    speaker reference of 2560 latents (640 keys), cfg_text 3 / cfg_speaker 8 — 3 of C2's 40 Euler steps, of which the first two
+    are 3-row CFG steps (t = 0.999, 0.666 >= 0.5) and the last a 1-row step; the CPU oracle needs ~20 s per step.  The fp32
+    engine must meet the north-star latent tolerance against the fp32 oracle on the same noise."""
+    cfg = R.DiTConfig()
+    w = R.make_dit_weights(cfg, seed=0, with_blockwise=False)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.zeros((1, 768), dtype=torch.int32)
+    ids[0, 1:436] = torch.randint(32, 127, (435,), generator=g, dtype=torch.int32)
+    tmask = torch.zeros((1, 768), dtype=torch.bool)
+    tmask[0, :436] = True
+    spk = torch.randn((1, 2560, 80), generator=g)
+    smask = torch.ones((1, 2560), dtype=torch.bool)
+    x0 = torch.randn((1, 640, 80), generator=torch.Generator().manual_seed(0))
+    kw = dict(num_steps=3, cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_min_t=0.5, cfg_max_t=1.0, truncation_factor=None,
+              rescale_k=None, rescale_sigma=None, speaker_kv_scale=None, speaker_kv_max_layers=None, speaker_kv_min_t=None)
+    torch.set_num_threads(16)
+    want = R.sample_euler(w, cfg, torch.float32, spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
+    m = E.EchoDiT(cfg, w, dtype=torch.float32, device=DEV)
+    got = E.sample_euler_cfg_independent_guidances(m, spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
+    e = rms(got, want)
+    print(f"C2 shapes, full depth, 3 steps with CFG: fp32 engine rms {e:.3e} vs fp32 oracle (latent rms {U.rms(want):.3f})")
+    assert e < LAT_TOL, (e, U.rms(want))
 
 
 @pytest.mark.parametrize("dname,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
