@@ -145,6 +145,8 @@ struct Engine : EngineBase {
   std::vector<void*> owned;                           // packed weights
 
   ~Engine() override {
+    if (nk_pinned) (void)hipHostFree(nk_pinned);
+    for (auto& e : nk_ev) if (e) (void)hipEventDestroy(e);
     for (void* p : owned) (void)hipFree(p);
     for (DevBuf* b : all_bufs()) b->release();
     b_gemm_ws.release(); b_tune_c.release(); b_flush.release();
@@ -686,9 +688,28 @@ struct Engine : EngineBase {
   }
 
   std::vector<int> host_nk = std::vector<int>(4 * MAXROWS, 0);
+  // The per-row key counts go to the device through a ring of pinned staging slots, without a host sync: the caller may
+  // enqueue the next sampler call while this one is still running (two requests in flight on two streams keep both
+  // streams fed).  A slot is reused only after the copy that read it has executed (its event).
+  static constexpr int NK_SLOTS = 16;
+  int* nk_pinned = nullptr;
+  hipEvent_t nk_ev[NK_SLOTS] = {};
+  bool nk_used[NK_SLOTS] = {};
+  int nk_next = 0;
   int push_nkeys(hipStream_t st) {
-    CK(hipMemcpyAsync(b_nkeys.p, host_nk.data(), host_nk.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    CK(hipStreamSynchronize(st));
+    const size_t bytes = host_nk.size() * sizeof(int);
+    if (!nk_pinned) {
+      CK(hipHostMalloc((void**)&nk_pinned, bytes * NK_SLOTS, hipHostMallocDefault));
+      for (auto& e : nk_ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = nk_next;
+    nk_next = (nk_next + 1) % NK_SLOTS;
+    if (nk_used[slot]) CK(hipEventSynchronize(nk_ev[slot]));
+    int* stage = nk_pinned + (size_t)slot * host_nk.size();
+    memcpy(stage, host_nk.data(), bytes);
+    CK(hipMemcpyAsync(b_nkeys.p, stage, bytes, hipMemcpyHostToDevice, st));
+    CK(hipEventRecord(nk_ev[slot], st));
+    nk_used[slot] = true;
     return ECHO_OK;
   }
   int push_nkeys_for_encoder(const std::vector<int>& nk, hipStream_t st) {
