@@ -46,8 +46,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
   return __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hbf16x8));   // 4 x v_cvt_pk_bf16_f32
 }
 
-// tile cursor carrying its segment's operands in scalar registers (refreshed only when the segment changes)
-struct TileIt { int seg, tile, nk; const char* kb; long kld; const char* vb; long vld; const float* bias; };
+// A stream walks the key tiles of the active segments in order.  Everything that changes per tile is one scalar pointer
+// advanced by a scalar step; the per-lane part of a DMA source address is a 32-bit offset that is recomputed only when
+// the stream enters a segment (and clamped on a segment's ragged last tile).  Three streams run 0 / 1 / 2 tiles ahead of
+// the compute tile: `cur` (mask information), `vs` (V of tile t + 1) and `ks` (K of tile t + 2).
+struct Stream { int seg, k0, nk; const char* ptr; int step; };
 
 // Software-pipelined by one tile: the Sᵀ = K·Qᵀ MFMAs of tile t+1 are issued before the softmax (VALU) of tile t
 // so the two overlap inside one wave; K tiles therefore run one tile ahead of V tiles in the LDS rings.
@@ -114,18 +117,10 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     }
   }
 #define SEL4(arr, s) ((s) == 0 ? arr[0] : (s) == 1 ? arr[1] : (s) == 2 ? arr[2] : arr[3])
-  auto enter_seg = [&](TileIt& it, int seg) {   // rare: only at segment boundaries
-    it.seg = seg; it.tile = 0; it.nk = NK(seg);
-    it.kb = SEL4(kb_, seg); it.kld = SEL4(kld_, seg); it.vb = SEL4(vb_, seg); it.vld = SEL4(vld_, seg); it.bias = SEL4(bias_, seg);
-  };
-  auto advance = [&](TileIt it) -> TileIt {
-    ++it.tile;
-    if (it.tile * KT >= it.nk) {
-      int sgn = it.seg + 1;
-      while (sgn < 4 && NK(sgn) == 0) ++sgn;
-      if (sgn < 4) enter_seg(it, sgn); else --it.tile;   // stay on the last tile
-    }
-    return it;
+  auto next_seg = [&](int sg) -> int {          // next segment with keys, 4 = none
+    ++sg;
+    while (sg < 4 && NK(sg) == 0) ++sg;
+    return sg;
   };
 
   char* const kring = smem;
@@ -139,27 +134,50 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     v_d[i] = (wid * 2 + i) * 8 + (lane >> 3);
     v_c[i] = ((lane & 7) ^ ((v_d[i] >> 1) & 7)) << 4;
   }
-  auto k_src = [&](const TileIt& it, const char* (&src)[2]) {
-    const int k0 = it.tile * KT, last = it.nk - 1;
+  // K stream: ptr = first key row of the tile; lane offset = (row of the piece, clamped to the segment's last key) * kld + chunk
+  Stream ks, vs, cur;
+  unsigned k_off[2], v_off[2];
+  auto k_offsets = [&]() {
+    const int kld = (int)SEL4(kld_, ks.seg), last = ks.nk - 1 - ks.k0;      // last >= 0
 #pragma unroll
-    for (int i = 0; i < 2; ++i) src[i] = it.kb + k_c[i] + (long)min(k0 + k_r[i], last) * it.kld;
+    for (int i = 0; i < 2; ++i) k_off[i] = (unsigned)(min(k_r[i], last) * kld + k_c[i]);
   };
-  auto v_src = [&](const TileIt& it, const char* (&src)[2]) {
-    const char* vbase = it.vb + it.tile * (KT * 2);
+  auto k_enter = [&](int sg) {
+    ks.seg = sg; ks.k0 = 0; ks.nk = NK(sg); ks.ptr = SEL4(kb_, sg); ks.step = (int)SEL4(kld_, sg) * KT;
+    k_offsets();
+  };
+  auto k_advance = [&]() {                       // past the end the stream stays on the last tile
+    if (ks.k0 + KT < ks.nk) {
+      ks.k0 += KT; ks.ptr += ks.step;
+      if (ks.k0 + KT > ks.nk) k_offsets();       // ragged last tile of the segment: clamp the rows
+    } else {
+      const int sg = next_seg(ks.seg);
+      if (sg < 4) k_enter(sg);
+    }
+  };
+  auto v_enter = [&](int sg) {
+    vs.seg = sg; vs.k0 = 0; vs.nk = NK(sg); vs.ptr = SEL4(vb_, sg); vs.step = KT * 2;
+    const int vld = (int)SEL4(vld_, sg);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) src[i] = vbase + v_c[i] + (long)v_d[i] * it.vld;
+    for (int i = 0; i < 2; ++i) v_off[i] = (unsigned)(v_d[i] * vld + v_c[i]);
   };
-  auto stage_k = [&](int slot, const TileIt& it) {
-    const char* src[2];
-    k_src(it, src);
+  auto v_advance = [&]() {
+    if (vs.k0 + KT < vs.nk) { vs.k0 += KT; vs.ptr += vs.step; }
+    else { const int sg = next_seg(vs.seg); if (sg < 4) v_enter(sg); }
+  };
+  const float* cur_bias = nullptr;
+  auto c_enter = [&](int sg) { cur.seg = sg; cur.k0 = 0; cur.nk = NK(sg); cur_bias = SEL4(bias_, sg); };
+  auto c_advance = [&]() {
+    if (cur.k0 + KT < cur.nk) cur.k0 += KT;
+    else { const int sg = next_seg(cur.seg); if (sg < 4) c_enter(sg); }
+  };
+  auto stage_k = [&](int slot) {
     char* kb = kring + slot * K_TILE_BYTES + wid * 2048;
-    glds16(src[0], kb); glds16(src[1], kb + 1024);
+    glds16(ks.ptr + k_off[0], kb); glds16(ks.ptr + k_off[1], kb + 1024);
   };
-  auto stage_v = [&](int slot, const TileIt& it) {
-    const char* src[2];
-    v_src(it, src);
+  auto stage_v = [&](int slot) {
     char* vb = vring + slot * V_TILE_BYTES + wid * 2048;
-    glds16(src[0], vb); glds16(src[1], vb + 1024);
+    glds16(vs.ptr + v_off[0], vb); glds16(vs.ptr + v_off[1], vb + 1024);
   };
 
   const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped
@@ -186,24 +204,23 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     for (int d = 0; d < 4; ++d) vf[d] = *(const bf16x8*)(sv + (d * 32 + fr) * 128 + ((chunk ^ sw_v) << 4));
   };
 
-  // masks this wave's half of tile `it` in place (register r is key k0 + 32kh + 16(r>>3) + 8fh + (r&7)); rare path
-  auto apply_mask = [&](f32x16& s, const TileIt& it) {
-    const int nk = it.nk, k0 = it.tile * KT;
-    const float* bias = it.bias;
+  // masks this wave's half of the current tile in place (register r is key k0 + 32kh + 16(r>>3) + 8fh + (r&7)); rare path
+  auto apply_mask = [&](f32x16& sc) {
+    const int nk = cur.nk, k0 = cur.k0;
+    const float* bias = cur_bias;
     const float inv_scale = 1.0f / p.scale;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 32 * kh + 16 * (r >> 3) + 8 * fh + (r & 7);
       bool ok = key < nk;
       if (CAUSAL) ok = ok && (key <= q);
-      float x = s[r];
+      float x = sc[r];
       if (BIAS) { if (bias) x += bias[ok ? key : 0] * inv_scale; }   // bias is added to the scaled score in the reference
-      s[r] = ok ? x : -INFINITY;
+      sc[r] = ok ? x : -INFINITY;
     }
   };
-  auto tile_needs_mask = [&](const TileIt& it) -> bool {
-    const int k0 = it.tile * KT;
-    return (k0 + KT > it.nk) || (BIAS && it.bias != nullptr) || (CAUSAL && (k0 + KT - 1 > qbase + qb * 32));
+  auto tile_needs_mask = [&]() -> bool {
+    return (cur.k0 + KT > cur.nk) || (BIAS && cur_bias != nullptr) || (CAUSAL && (cur.k0 + KT - 1 > qbase + qb * 32));
   };
 
   // One pipeline step: Sᵀ(t+1) for this wave's keys (8 MFMAs) paired with the first 8 exponentials of tile t, the first
@@ -211,8 +228,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   // shadow work, at most one DMA piece} group: left alone hipcc hoists the LDS-DMA pieces into a burst (which blocks
   // the wave) and clusters the MFMAs.  On the last tile the "next" K slot holds a stale but valid tile whose Sᵀ is
   // computed and dropped (no branch, small code).
-  auto compute = [&](f32x16& scur, f32x16& snext, const char* sk_next, const char* sv,
-                     const char* (&ksrc)[2], char* kdst, const char* (&vsrc)[2], char* vdst) {
+  auto compute = [&](f32x16& scur, f32x16& snext, const char* sk_next, const char* sv, char* kdst, char* vdst) {
     bf16x8 kf[8], vf0[4], vf1[4];
     load_k(sk_next, kf);
     load_v(sv, 0, vf0);
@@ -243,10 +259,10 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     for (int kk = 0; kk < 8; ++kk) {
       snext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], snext, 0, 0, 0);
       { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kk], c, -mc)); scur[kk] = pv; rs += pv; }
-      if (kk == 1) glds16(ksrc[0], kdst);            // K(t+2)
-      if (kk == 3) glds16(ksrc[1], kdst + 1024);
-      if (kk == 5) glds16(vsrc[0], vdst);            // V(t+1)
-      if (kk == 7) glds16(vsrc[1], vdst + 1024);
+      if (kk == 1) glds16(ks.ptr + k_off[0], kdst);            // K(t+2)
+      if (kk == 3) glds16(ks.ptr + k_off[1], kdst + 1024);
+      if (kk == 5) glds16(vs.ptr + v_off[0], vdst);            // V(t+1)
+      if (kk == 7) glds16(vs.ptr + v_off[1], vdst + 1024);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -272,16 +288,15 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   };
 
   if (total_tiles > 0) {
-    TileIt it0;
     {
       int s0 = 0;
       while (s0 < 3 && NK(s0) == 0) ++s0;
-      enter_seg(it0, s0);
+      k_enter(s0); v_enter(s0); c_enter(s0);
     }
-    TileIt it1 = advance(it0);
-    stage_k(0, it0);
-    stage_v(0, it0);
-    if (total_tiles > 1) stage_k(1, it1);
+    stage_k(0);                       // K(0)
+    stage_v(0);                       // V(0)
+    k_advance();
+    if (total_tiles > 1) stage_k(1);  // K(1)
     __syncthreads();   // vmcnt(0) + barrier
     f32x16 sa, sb;
     {
@@ -292,7 +307,8 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sa, 0, 0, 0);
     }
-    TileIt it_cur = it0, it_nxt = it1, it_nn = advance(it1);
+    k_advance();                      // ks -> tile 2, vs -> tile 1, cur = tile 0
+    v_advance();
     // tile t is in `sa`; Sᵀ of tile t+1 is produced into `sb` and moved over at the end of the step
 #pragma unroll 1
     for (int t = 0; t < total_tiles; ++t) {
@@ -305,19 +321,16 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       if (PROF) { const unsigned long long tv = stamp(); pt[4] += tv - t0; }
       __syncthreads();   // K(t+1), V(t) landed; every wave finished QK(t) and PV(t-1)
       if (PROF) t1 = stamp();
-      // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the cursors stay on the last
+      // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the streams stay on the last
       // tile: the redundant pieces land in slots nobody reads again (and are drained before the merge).
-      const char* ksrc[2]; const char* vsrc[2];
-      k_src(it_nn, ksrc);
-      v_src(it_nxt, vsrc);
       char* kdst = kring + (t & 1) * K_TILE_BYTES + wid * 2048;
       char* vdst = vring + ((t + 1) & 1) * V_TILE_BYTES + wid * 2048;
-      if (tile_needs_mask(it_cur)) apply_mask(sa, it_cur);
+      if (tile_needs_mask()) apply_mask(sa);
       if (PROF) t2 = stamp();
-      compute(sa, sb, kring + ((t + 1) & 1) * K_TILE_BYTES, vring + (t & 1) * V_TILE_BYTES, ksrc, kdst, vsrc, vdst);
+      compute(sa, sb, kring + ((t + 1) & 1) * K_TILE_BYTES, vring + (t & 1) * V_TILE_BYTES, kdst, vdst);
       if (PROF) { const unsigned long long t3 = stamp(); pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += 1; }
       sa = sb;
-      it_cur = it_nxt; it_nxt = it_nn; it_nn = advance(it_nn);
+      k_advance(); v_advance(); c_advance();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the rings are reused / the workgroup ends
