@@ -70,6 +70,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <bool CAUSAL, bool BIAS, bool PROF>
 __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long k_t0 = 0, k_r0 = 0, pa = 0, pb = 0;
+  if (PROF) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,9 +93,13 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 
   // ---- per-segment key counts (wave-uniform); explicit selects instead of runtime-indexed arrays
   const int q_hi = min(qbase + QT, p.S) - 1;
-  auto seg_keys = [&](int s) -> int {
-    if (s >= p.nseg) return 0;
-    int nk = p.seg[s].nkeys[row];
+  // all four counts are requested at once (independent scalar loads; inactive segments read segment 0's slot and are
+  // zeroed afterwards): a branchy per-segment version serialised four dependent ~1 k-cycle round trips per workgroup
+  int nkraw[4];
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) nkraw[sgi] = (sgi < p.nseg ? p.seg[sgi].nkeys : p.seg[0].nkeys)[row];
+  auto seg_keys = [&](int sgi) -> int {
+    int nk = sgi < p.nseg ? nkraw[sgi] : 0;
     if (CAUSAL) nk = min(nk, q_hi + 1);
     return nk < 0 ? 0 : nk;
   };
@@ -104,12 +110,17 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   // ---- per-segment operands resolved ONCE into scalar registers (indexing the kernel-argument struct inside the tile
   // loop costs a chain of s_load + s_waitcnt per use: measured 1800 cycles per tile)
   const char* kb_[4]; const char* vb_[4]; long kld_[4], vld_[4]; const float* bias_[4];
+  int mod0 = 0;     // the shared-KV segments all use the same modulus (the batch size): divide once
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi)
+    if (sgi < p.nseg && mod0 == 0 && p.seg[sgi].kv_mod > 0) mod0 = p.seg[sgi].kv_mod;
+  const int rmod0 = mod0 > 0 ? row % mod0 : row;
 #pragma unroll
   for (int sgi = 0; sgi < 4; ++sgi) {
     kb_[sgi] = nullptr; vb_[sgi] = nullptr; kld_[sgi] = 0; vld_[sgi] = 0; bias_[sgi] = nullptr;
     if (sgi < p.nseg) {
       const AttnSeg& sg = p.seg[sgi];
-      const int kvrow = sg.kv_mod ? row % sg.kv_mod : row;
+      const int kvrow = sg.kv_mod == 0 ? row : (sg.kv_mod == mod0 ? rmod0 : row % sg.kv_mod);   // one division per workgroup in practice
       kb_[sgi] = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
       vb_[sgi] = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
       kld_[sgi] = sg.k_ld * 2; vld_[sgi] = sg.vt_ld * 2;
@@ -287,6 +298,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     l_i += rs;
   };
 
+  if (PROF) pa = stamp() - k_t0;      // Q fragments requested, key counts and segment operands resolved
   if (total_tiles > 0) {
     {
       int s0 = 0;
@@ -298,6 +310,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     k_advance();
     if (total_tiles > 1) stage_k(1);  // K(1)
     __syncthreads();   // vmcnt(0) + barrier
+    if (PROF) pb = stamp() - k_t0;    // first K / V tiles landed
     f32x16 sa, sb;
     {
       bf16x8 kf[8];
@@ -309,6 +322,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     }
     k_advance();                      // ks -> tile 2, vs -> tile 1, cur = tile 0
     v_advance();
+    if (PROF) pt[7] = __builtin_amdgcn_s_memtime() - k_t0;   // prologue
     // tile t is in `sa`; Sᵀ of tile t+1 is produced into `sb` and moved over at the end of the step
 #pragma unroll 1
     for (int t = 0; t < total_tiles; ++t) {
@@ -337,6 +351,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   if (PROF && lane == 0) {
     unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wid) * 8;
     dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4];
+    dst[5] = __builtin_amdgcn_s_memtime() - k_t0; dst[6] = __builtin_amdgcn_s_memrealtime() - k_r0; dst[7] = pt[7] | (pa << 20) | (pb << 40);   // up to the end of the tile loop
   }
 
   // ---- merge the two key halves of each query block: waves kh = 1 park (O, m, l) in LDS, waves kh = 0 combine

@@ -34,6 +34,8 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     for _ in range(3):
         L.check(lib.echo_op_attention_bf16(C.byref(d), U.stream()))
     torch.cuda.synchronize()
+    for _ in range(60):      # settle the clock under load
+        lib.echo_op_attention_bf16(C.byref(d), U.stream())
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -52,6 +54,10 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=20):
     tiles = pr[:, 3].clamp_min(1)
     print("   per-tile cycles (mean over waves): vmcnt+barrier %.0f (of which vmcnt(0) wait %.0f)  issue+mask %.0f  compute %.0f   | tiles/wave mean %.1f max %.0f" %
           ((pr[:, 0] / tiles).mean(), (pr[:, 4] / tiles).mean(), (pr[:, 1] / tiles).mean(), (pr[:, 2] / tiles).mean(), tiles.mean(), tiles.max()))
+    print("   per-wave cycles from kernel start to the end of the tile loop: mean %.0f (tile loop accounts for %.0f); clock %.2f GHz; prologue %.0f" %
+          (pr[:, 5].mean(), (pr[:, 0] + pr[:, 1] + pr[:, 2]).mean(), (pr[:, 5] / (pr[:, 6] / 100e6)).mean() / 1e9, (pr[:, 7].long() & 0xFFFFF).double().mean()))
+    x = prof.cpu()[:, 7]
+    print('   prologue split: setup (args, key counts, Q requested) %.0f | first tiles landed %.0f | first QK done %.0f' % (((x >> 20) & 0xFFFFF).double().mean(), ((x >> 40) & 0xFFFFF).double().mean(), (x & 0xFFFFF).double().mean()))
     big = pr[pr[:, 3] == pr[:, 3].max()]
     print("   longest waves: barrier %.0f issue %.0f compute %.0f (cycles per tile)" % tuple((big[:, i] / big[:, 3]).mean() for i in range(3)))
 
