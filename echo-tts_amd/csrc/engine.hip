@@ -262,11 +262,12 @@ struct Engine : EngineBase {
         CK(b_flush.reserve((size_t)512 << 20));
         float best_ms = 1e30f;
         for (int cfg = 0; cfg < gemm_num_cfgs(); ++cfg) {
+          if (cfg >= 6 && (g.qkv_mode || g.N % 96 != 0)) continue;   // 192 / 96-column tiles: only where they divide N
           for (int ksp = 1; ksp <= 8; ksp *= 2) {
             if (ksp > 1 && (g.nbatch > 1 || g.qkv_mode || nk / ksp < 4 || t128 * ksp > 1024)) continue;
             t.cfg = cfg; t.ksplit = ksp;
             if (ksp > 1) {
-              const long need = (long)ksp * (((long)g.M + 255) / 256 * 256) * g.Npad * 4;
+              const long need = (long)ksp * (((long)g.M + 767) / 768 * 768) * g.Npad * 4   /* rows padded for every tile height (128, 256, 384) */;
               CK(b_gemm_ws.reserve((size_t)need));
               t.ws = b_gemm_ws.p; t.ws_bytes = (long)b_gemm_ws.cap;
             }
@@ -299,7 +300,7 @@ struct Engine : EngineBase {
     g.cfg = it->second.cfg;
     g.ksplit = it->second.ksplit;
     if (g.ksplit > 1) {
-      const long need = (long)g.ksplit * (((long)g.M + 255) / 256 * 256) * g.Npad * 4;
+      const long need = (long)g.ksplit * (((long)g.M + 767) / 768 * 768) * g.Npad * 4   /* rows padded for every tile height (128, 256, 384) */;
       CK(b_gemm_ws.reserve((size_t)need));
       g.ws = b_gemm_ws.p; g.ws_bytes = (long)b_gemm_ws.cap;
     }

@@ -123,6 +123,13 @@ __device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, co
 // the last barrier): the owning waves write their accumulators as 16-byte chunks into a [32][BN/4] fp32 slab
 // (chunk ^= row, conflict spreading; `put(pass, slab)`), then all threads re-read it row-wise so that consecutive lanes
 // cover consecutive columns of one row: global stores are whole row segments and the fused tail is emitted once.
+// position of 16-byte chunk `chunk` of slab row `ml` (conflict spreading): XOR for power-of-two rows, rotation otherwise
+template <int CPR>
+__device__ __forceinline__ int slab_pos(int ml, int chunk) {
+  if constexpr ((CPR & (CPR - 1)) == 0) return ml * CPR + (chunk ^ ml);
+  else return ml * CPR + (chunk + ml) % CPR;
+}
+
 // cycle accounting of the diagnostic build (s_memtime sums per wave; compiled out unless PROF)
 struct EpiProf { unsigned long long t_bar1 = 0, t_put = 0, t_bar2 = 0, t_rw = 0; };
 #define EPI_STAMP(var) do { if constexpr (PROF) { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); prof->var += n__ - last__; last__ = n__; } } while (0)
@@ -157,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
       for (int idx = tid; idx < 32 * CPR; idx += NT) {
         const int ml = idx / CPR, chunk = idx % CPR;
         if (tile_n * BN + chunk * 4 < p.Npad)
-          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
       }
     } else if constexpr (SWIGLU) {
       // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
@@ -168,8 +175,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         const int m = mrow0 + ml;
         const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
         if (m >= p.M || j0 >= (p.N >> 1)) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + q) ^ ml)) * 4);
-        const f32x4 b4 = *(const f32x4*)(slab + (ml * CPR + ((b * 8 + 4 + q) ^ ml)) * 4);
+        const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, b * 8 + q) * 4);
+        const f32x4 b4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, b * 8 + 4 + q) * 4);
         swiglu_tail<T>(p, m, j0, a4, b4, C);
       }
     } else if (p.qkv_mode) {
@@ -186,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             const int rw = 8 * sg + r;
-            v8[r] = Num<T>::rnd(slab[(rw * CPR + ((col >> 2) ^ rw)) * 4 + (col & 3)]);
+            v8[r] = Num<T>::rnd(slab[slab_pos<CPR>(rw, col >> 2) * 4 + (col & 3)]);
           }
           const int hd = tile_n * BN + col - 2 * D;        // h * 128 + d
           const int b = m / p.qkv_S, sidx = m - b * p.qkv_S;
@@ -207,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
           const int ml = idx / CPR, chunk = idx % CPR;
           const int m = mrow0 + ml;
           const int n0 = tile_n * BN + chunk * 4;
-          const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+          const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
           float y[4] = {Num<T>::rnd(a4[0]), Num<T>::rnd(a4[1]), Num<T>::rnd(a4[2]), Num<T>::rnd(a4[3])};
           if (sec < 2) {
             // 32 consecutive lanes hold the 128 columns of one (token, head): half-wave reduction of the squares
@@ -241,7 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         const int m = mrow0 + ml;
         const int n0 = tile_n * BN + chunk * 4;
         if (m >= p.M || n0 >= p.N) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + (ml * CPR + (chunk ^ ml)) * 4);
+        const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
         float y[4] = {a4[0], a4[1], a4[2], a4[3]};
         gemm_tail<T>(p, m, n0, y, zo, zi, C, C2);
       }
@@ -261,7 +268,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
   constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, PPW = CF::PPW, STAGES = CF::STAGES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Npad + BN - 1) / BN;
+  // column tiles cover N (the packed SwiGLU rows: Npad); a tile that lies wholly in the row padding of W is not launched
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = ((SWIGLU ? p.Npad : p.N) + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {  // bijective XCD remap: workgroups that share an XCD (bid % 8) get a contiguous run of tiles
@@ -359,10 +367,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
     // spread over the tile instead of being hoisted into one burst
     auto after_mfma = [&]() {
       ++mf;
-      if (piece < PPW && mf * PPW * DMA_SPREAD_DEN >= (piece + 1) * NMF) {   // all pieces go out in the first 1/DMA_SPREAD_DEN of the tile
-        if (more) glds16(nsrc[piece], ndst + piece * 1024);
-        ++piece;
-        __builtin_amdgcn_sched_barrier(0);
+      // all pieces go out in the first 1/DMA_SPREAD_DEN of the tile (more than one per call where a wave has more
+      // pieces than MFMA groups, e.g. the 128x96 split3 tile: 7 pieces, 6 groups)
+#pragma unroll
+      for (int due = 0; due < PPW; ++due) {
+        if (piece < PPW && mf * PPW * DMA_SPREAD_DEN >= (piece + 1) * NMF) {
+          if (more) glds16(nsrc[piece], ndst + piece * 1024);
+          ++piece;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     };
     if constexpr (Num<T>::is_bf16) {
@@ -457,7 +470,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
           const int chunk = wn * (CF::WN / 4) + tn * 8 + 2 * g + fh_;
           f32x4 v;
           v[0] = a[4 * g]; v[1] = a[4 * g + 1]; v[2] = a[4 * g + 2]; v[3] = a[4 * g + 3];
-          *(f32x4*)(slab + (fr_ * CPR + (chunk ^ fr_)) * 4) = v;
+          *(f32x4*)(slab + slab_pos<CPR>(fr_, chunk) * 4) = v;
         }
       };
 #pragma unroll
@@ -1078,7 +1091,7 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = (g.Npad + CF::BN - 1) / CF::BN;
+  const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = ((SW ? g.Npad : g.N) + CF::BN - 1) / CF::BN;
   const int ks = g.ksplit > 1 ? g.ksplit : 1;
   dim3 grid(tiles_m * tiles_n, g.nbatch, ks);
   hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::SMEM, st, g);
@@ -1135,13 +1148,21 @@ typedef TileCfg<128, 128, 2, 2, 4> Cfg1;   // 4 waves, 128 KiB, 3 tiles in fligh
 typedef TileCfg<256, 256, 2, 4, 2> Cfg2;   // 8 waves (128x64 each), 128 KiB: lowest L2 traffic per FLOP
 typedef TileCfg<256, 128, 4, 2, 3> Cfg3;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
 typedef TileCfg<128, 256, 2, 4, 3> Cfg4;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
+typedef TileCfg<128, 192, 2, 2, 2> Cfg6;   // 4 waves (64x96 each), 80 KiB: N = 192 / 384 without padding waste (DAC 192- and 384-channel convs)
+typedef TileCfg<128, 96, 4, 1, 2> Cfg7;    // 4 waves (32x96 each), 56 KiB: N = 96 (DAC 96-channel convs)
+typedef TileCfg<256, 192, 4, 2, 2> Cfg8;   // 8 waves (64x96 each), 112 KiB: less L2->LDS traffic per output for the long-M convs
+typedef TileCfg<384, 96, 6, 1, 2> Cfg9;    // 6 waves (64x96 each), 120 KiB: N = 96, the weight tile amortised over 384 rows
 
 template <typename T, bool SW>
 hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
   if constexpr (!Num<T>::is_bf16) {
-    if (g.cfg >= 5) return hipErrorInvalidValue;   // the ping-pong kernel (and its diagnostic builds) is bf16 only
+    if (g.cfg == 5 || g.cfg >= 100) return hipErrorInvalidValue;   // the ping-pong kernel (and its diagnostic builds) is bf16 only
     if (g.split3) {
       switch (g.cfg) {
+        case 6: return launch_cfg<T, SW, Cfg6, true>(g, st);
+        case 7: return launch_cfg<T, SW, Cfg7, true>(g, st);
+        case 8: return launch_cfg<T, SW, Cfg8, true>(g, st);
+        case 9: return launch_cfg<T, SW, Cfg9, true>(g, st);
         case 1: return launch_cfg<T, SW, Cfg1, true>(g, st);
         case 2: return launch_cfg<T, SW, Cfg2, true>(g, st);
         case 3: return launch_cfg<T, SW, Cfg3, true>(g, st);
@@ -1175,19 +1196,24 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
     }
     return hipErrorInvalidValue;
   }
+  if (g.cfg >= 6 && g.qkv_mode) return hipErrorInvalidValue;   // the fused QKV tail needs tiles that divide a section (BN | D)
   switch (g.cfg) {
     case 1: return launch_cfg<T, SW, Cfg1>(g, st);
     case 2: return launch_cfg<T, SW, Cfg2>(g, st);
     case 3: return launch_cfg<T, SW, Cfg3>(g, st);
     case 4: return launch_cfg<T, SW, Cfg4>(g, st);
+    case 6: return launch_cfg<T, SW, Cfg6>(g, st);
+    case 7: return launch_cfg<T, SW, Cfg7>(g, st);
+    case 8: return launch_cfg<T, SW, Cfg8>(g, st);
+    case 9: return launch_cfg<T, SW, Cfg9>(g, st);
     default: return launch_cfg<T, SW, Cfg0>(g, st);
   }
 }
 
 }  // namespace
 
-int gemm_tile_m(int cfg) { return cfg == 2 || cfg == 3 || cfg >= 5 ? 256 : 128; }
-int gemm_num_cfgs() { return 6; }
+int gemm_tile_m(int cfg) { return cfg == 9 ? 384 : cfg == 2 || cfg == 3 || cfg == 5 || cfg == 8 || cfg >= 100 ? 256 : 128; }
+int gemm_num_cfgs() { return 10; }
 
 template <typename T>
 hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {

@@ -60,7 +60,7 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     elif ksplit > 1:
-        need = ksplit * ((M + 255) // 256 * 256) * d.Npad * 4
+        need = ksplit * ((M + 767) // 768 * 768) * d.Npad * 4   # rows padded for every tile height (128 / 256 / 384)
         ws = torch.empty((need,), dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = ws.data_ptr(), need
     L.check(lib().echo_op_gemm(code(A), C.byref(d), stream()))

@@ -289,7 +289,7 @@ def test_transpose_heads(dt, HD):
     assert bool((vt[..., S:] == 0).all())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9])
 @pytest.mark.parametrize("ksplit", [1, 2, 4])
 def test_gemm_all_tile_configs_and_splitk(cfg, ksplit):
     """Every tile configuration / pipeline depth / split-K factor gives the same result (bf16 epilogue, fp32 taps, SwiGLU)."""
@@ -381,7 +381,7 @@ def test_gemm_pingpong_deterministic_and_exact_on_integers():
     assert torch.equal(outs[0], ref.bfloat16())
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4])
+@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 7, 8, 9])
 def test_gemm_f32_split3_accuracy(cfg):
     """fp32 GEMM on 3 bf16 MFMAs per product: relative error ~1e-5 of the exact result (used by the DAC decoder)."""
     M, N, K = 300, 256, 1024
