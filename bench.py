@@ -154,7 +154,7 @@ def main() -> None:
     ap.add_argument("--concurrency", type=int, default=2,
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
@@ -261,7 +261,7 @@ def main() -> None:
         single = {"value": round(AUDIO_S / (best * 1e-3), 3), "unit": "audio-s/s", "ms_per_utterance": round(best, 2),
                   "workload": "C2: one utterance per sampler call (M = 1920 / 640 GEMM rows)"}
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg belongs to the N=1 line only
         cpu = cpu_baseline(host_threads())
 
     if rank == 0:

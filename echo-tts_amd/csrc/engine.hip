@@ -263,8 +263,10 @@ struct Engine : EngineBase {
         float best_ms = 1e30f;
         for (int cfg = 0; cfg < gemm_num_cfgs(); ++cfg) {
           if (cfg >= 6 && (g.qkv_mode || g.N % 96 != 0)) continue;   // 192 / 96-column tiles: only where they divide N
-          for (int ksp = 1; ksp <= 8; ksp *= 2) {
-            if (ksp > 1 && (g.nbatch > 1 || g.qkv_mode || nk / ksp < 4 || t128 * ksp > 1024)) continue;
+          // split-K factors: 3 and 6 matter for the 256-CU grid (e.g. 160 tiles x 3 = 1.875 rounds instead of 0.625)
+          static const int kKsplits[] = {1, 2, 3, 4, 6, 8};
+          for (int ksp : kKsplits) {
+            if (ksp > 1 && (g.nbatch > 1 || g.qkv_mode || nk / ksp < 4 || t128 * ksp > 4096)) continue;
             t.cfg = cfg; t.ksplit = ksp;
             if (ksp > 1) {
               const long need = (long)ksp * (((long)g.M + 767) / 768 * 768) * g.Npad * 4   /* rows padded for every tile height (128, 256, 384) */;

@@ -148,6 +148,29 @@ def test_blockwise_sampler_f32(golden, tiny_models, case, opts, cont):
     assert e < LAT_TOL, e
 
 
+def test_invalid_arguments_fail_loudly_and_the_context_survives(golden, tiny_models):
+    """Error behaviour at the boundary (SURVEY.md §8b "Errors"): a bad call returns a status, the shim raises with
+    echo_last_error's text, nothing is left half-done - the same context then reproduces the golden sampler run."""
+    g, m = golden, tiny_models["f32"]
+    ids, tm = g["tiny.ids"], g["tiny.tmask"].bool()
+    spk, sm = g["tiny.spk"], g["tiny.smask"].bool()
+    with pytest.raises(RuntimeError, match="multiple of the patch size"):
+        m.get_kv_cache_speaker(spk[:, :-1], sm[:, :-1])           # the reference's reshape (model.py:455) raises here too
+    kvt, kvs = m.get_kv_cache_text(ids, tm), m.get_kv_cache_speaker(spk, sm)
+    x0 = g["tiny.x0"]
+    with pytest.raises(NotImplementedError):                      # rows of one forward share the timestep
+        m(torch.cat([x0, x0], 0), torch.tensor([0.7, 0.6]), torch.cat([tm, tm], 0), torch.cat([sm, sm], 0),
+          _concat_kv_caches(kvt, kvt), _concat_kv_caches(kvs, kvs))
+    with pytest.raises(RuntimeError, match="rope table too short"):
+        E.sample_euler_cfg_independent_guidances(m, spk, sm, ids, tm, rng_seed=0, sequence_length=100000, **SAMPLER_CASES["cfg_default"])
+    b2 = (g["tinyb2.ids"], g["tinyb2.tmask"].bool(), g["tinyb2.spk"], g["tinyb2.smask"].bool())
+    kvt2, kvs2 = m.get_kv_cache_text(b2[0], b2[1]), m.get_kv_cache_speaker(b2[2], b2[3])
+    with pytest.raises(ValueError, match="multiple of the KV batch"):
+        m(torch.cat([x0, x0, x0], 0), torch.full((3,), 0.7), torch.cat([b2[1], b2[1][:1]], 0), torch.cat([b2[3], b2[3][:1]], 0), kvt2, kvs2)
+    lat = E.sample_euler_cfg_independent_guidances(m, spk, sm, ids, tm, rng_seed=0, sequence_length=32, x_init=x0, **SAMPLER_CASES["cfg_default"])
+    assert rms(lat, g["tiny.f32.euler.cfg_default"]) <= LAT_TOL
+
+
 def test_sampler_is_deterministic(golden, tiny_models):
     g, m = golden, tiny_models["bf16"]
     args = (m, g["tiny.spk"], g["tiny.smask"].bool(), g["tiny.ids"], g["tiny.tmask"].bool())

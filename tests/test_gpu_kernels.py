@@ -325,7 +325,7 @@ def test_gemm_all_tile_configs_and_splitk(cfg, ksplit):
     assert (o3.double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("ksplit", [1, 2, 4])
+@pytest.mark.parametrize("ksplit", [1, 2, 3, 4])
 def test_gemm_pingpong_matches_torch(ksplit):
     """gemm_pp_kernel (cfg 5: 256x256 tile, 16x16x32 MFMA, staggered wave groups): ragged M / N, short and long K,
     bf16 epilogue, SwiGLU, and a dilated bf16 conv through the taps loop, against fp32 torch + the same rounding points."""
