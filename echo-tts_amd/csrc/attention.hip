@@ -408,17 +408,12 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   if (a.causal && a.nseg != 1) return hipErrorInvalidValue;
   for (int s = 0; s < a.nseg; ++s)
     if ((a.seg[s].vt_ld & 7) || (a.seg[s].k_ld & 7) || !a.seg[s].nkeys) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* ks[] = {(const void*)attn_kernel<false, false, false>, (const void*)attn_kernel<true, false, false>,
-                        (const void*)attn_kernel<false, true, false>, (const void*)attn_kernel<true, true, false>,
-                        (const void*)attn_kernel<false, false, true>};
-    for (const void* k : ks) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> prepared[5];
+  const void* ks[5] = {(const void*)attn_kernel<false, false, false>, (const void*)attn_kernel<true, false, false>,
+                       (const void*)attn_kernel<false, true, false>, (const void*)attn_kernel<true, true, false>,
+                       (const void*)attn_kernel<false, false, true>};
+  for (int i = 0; i < 5; ++i)
+    if (hipError_t e = ensure_dyn_lds(ks[i], SMEM, prepared[i]); e != hipSuccess) return e;
   dim3 grid((a.S + QT - 1) / QT, a.H, a.rows);
   bool bias = false;
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;

@@ -3,7 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
 #include <string>
+
+// hipFuncSetAttribute acts on the current device's copy of a kernel: `done` remembers (one bit per device ordinal) where
+// the dynamic-LDS limit of `kern` has been raised, so that a process driving several GPUs prepares each of them.
+inline hipError_t ensure_dyn_lds(const void* kern, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;

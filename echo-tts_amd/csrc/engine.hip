@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,7 +18,8 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Plan { int cfg = 0, ksplit = 1; };
-std::map<int, std::map<std::vector<long>, Plan>> g_plans;   // device -> (shape key -> plan); engines are used from one thread
+std::map<int, std::map<std::vector<long>, Plan>> g_plans;   // device -> (shape key -> plan), shared by every context of the process
+std::mutex g_plans_mu;                                       // contexts may be driven from different host threads (ctypes drops the GIL)
 
 inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 
@@ -226,7 +228,12 @@ struct Engine : EngineBase {
   // ------------------------------------------------------------------ GEMM plans (tile config + split-K per shape)
   // plans are shared by every context of the process on the same device (a second engine context of a serving process
   // must not re-tune while the first one is already running kernels: its timings would be garbage)
-  std::map<std::vector<long>, Plan>& plans = g_plans[device_key()];
+  std::map<std::vector<long>, Plan>& plans = plans_of_device();
+  static std::map<std::vector<long>, Plan>& plans_of_device() {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    int d = 0; (void)hipGetDevice(&d);
+    return g_plans[d];
+  }
   int device_key() { int d = 0; (void)hipGetDevice(&d); return d; }
   DevBuf b_gemm_ws, b_tune_c, b_flush;
   bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : true;
@@ -235,6 +242,7 @@ struct Engine : EngineBase {
   int plan_gemm(GemmArgs& g, hipStream_t st) {
     const int KEu = 128 / (int)sizeof(U);
     const std::vector<long> key = {g.M, g.N, g.K, g.taps, g.swiglu, g.nbatch, (long)sizeof(U), g.qkv_mode, g.split3};
+    std::lock_guard<std::mutex> lk(g_plans_mu);   // lookup, tuning and insertion are one critical section
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan best;

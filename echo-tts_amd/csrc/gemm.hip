@@ -1084,13 +1084,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs p, in
 
 template <typename T, bool SW, typename CF, bool SPLIT3 = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> prepared{0};
   auto kern = gemm_nt_kernel<T, SW, CF, SPLIT3>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_dyn_lds((const void*)kern, CF::SMEM, prepared); e != hipSuccess) return e;
   const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = ((SW ? g.Npad : g.N) + CF::BN - 1) / CF::BN;
   const int ks = g.ksplit > 1 ? g.ksplit : 1;
   dim3 grid(tiles_m * tiles_n, g.nbatch, ks);
@@ -1104,14 +1100,18 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
 }
 
 int pp_num_cus() {
-  static int n = 0;
+  static std::atomic<int> cached[64];          // per device ordinal; 0 = not queried yet
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& slot = cached[dev & 63];
+  int n = slot.load(std::memory_order_relaxed);
   if (!n) {
-    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     if (n <= 0) n = 256;
     n &= ~7;                                   // a multiple of the 8 XCDs (tile_of)
     if (const char* e = getenv("ECHO_PP_GRID")) { const int v = atoi(e); if (v >= 8) n = v & ~7; }
+    slot.store(n, std::memory_order_relaxed);
   }
   return n;
 }
@@ -1121,14 +1121,10 @@ hipError_t launch_pp(const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   static const int env_gn = getenv("ECHO_PP_GN") ? atoi(getenv("ECHO_PP_GN")) : 0;
   if (g.pp_gn <= 0 && env_gn > 0) g.pp_gn = env_gn;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> prepared{0};
   auto kern = gemm_pp_kernel<SW, DIAG, LEAD>;
   constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_dyn_lds((const void*)kern, SMEM, prepared); e != hipSuccess) return e;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.Npad + 255) / 256;
   const int ntiles = tiles_m * tiles_n;
   const int ks = g.ksplit > 1 ? g.ksplit : 1;
