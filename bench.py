@@ -12,7 +12,7 @@ synthetic (1, 2560, 80) latent.
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step runs `--batch` (default 4 = BASELINE config C3's per-GPU share: 32 utterances over 8 GPUs) independent
+A step runs `--batch` (default 8; BASELINE config C3's per-GPU share is 4, `--batch 4`) independent
 utterances through ONE sampler call, using the reference sampler's own batch axis (inference.py:448-449: text ids
 (B, Tt), speaker latents (B, Ts, 80), one noise draw of (B, S, 80)): the EchoDiT GEMMs then see M = 3*B*640 rows in
 the CFG steps and B*640 in the others, which is what fills 256 CUs with 256x256 tiles.  `--batch 1` is the
@@ -20,6 +20,7 @@ single-request configuration (C2 proper); its throughput is measured in the same
 `single_request`.  `--concurrency` (default 2) such calls are kept in flight on separate HIP streams / engine contexts,
 as a serving process does with independent requests (handler.py:747-759): the second call's kernels fill the CUs that
 the last, partial round of 256x256 tiles of the first leaves idle (+6 % measured; `--concurrency 1` for one call).
+Measured sweep (audio-s/s, batch x concurrency): 1x1 97, 4x1 134, 4x2 148, 8x2 157, 12x2 160, 16x2 161.
 
 Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
 utterances); the only collective in the job is the start-up broadcast of the frozen weights from
@@ -225,7 +226,7 @@ def main() -> None:
         traffic, traffic_src = None, None
         try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected inside this process)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
-            traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm.json (2 x FETCH_SIZE + WRITE_SIZE, KiB, batch 4)"
+            traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm.json (2 x FETCH_SIZE + WRITE_SIZE, KiB; rocprofv3 --pmc passes of this command at the default batch)"
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (bf16 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
