@@ -147,8 +147,8 @@ typedef struct {
   const void* res; int64_t ldres, res_bo, res_bi;
   const void* snake_alpha;
   int store_main, swiglu;
-  int cfg;                       /* tile configuration 0..4 (csrc/gemm.hip TileCfg table) */
-  int ksplit; void* ws; int64_t ws_bytes;   /* split-K: fp32 workspace of ksplit * roundup(M,256) * Npad * 4 bytes */
+  int cfg;                       /* plan: 0..4, 6..9 tile configurations (csrc/gemm.hip TileCfg table), 5 = bf16 ping-pong kernel */
+  int ksplit; void* ws; int64_t ws_bytes;   /* split-K: fp32 workspace of ksplit * roundup(M,768) * Npad * 4 bytes */
   int split3;                    /* fp32 only: 3 x bf16 MFMA per product (hi/lo operand splitting), ~1e-5 relative error */
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);

@@ -437,3 +437,14 @@ def test_attention_is_deterministic_at_full_size(R):
     ref = (ref.bfloat16().float() * torch.sigmoid(qkvg[:S, 3 * D:3 * D + 128].float()).bfloat16().float())
     err = (outs[0][:S, :128].float() - ref).abs()
     assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3
+
+
+def test_plain_c_caller_runs_through_the_abi(tmp_path):
+    """tests/c_abi/abi_smoke.c: a C11 program (no Python, no torch) drives echo_op_gemm through include/echo_hip.h; exact
+    integer GEMM, refused bad descriptor, error text.  One short-lived child process on the GPU."""
+    import subprocess
+    from tests.test_host_cpu import _build_c_caller
+    exe = _build_c_caller(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi_smoke: ok" in r.stdout

@@ -129,3 +129,24 @@ def test_handler_helpers_kat(golden):
     assert fn.keywords["num_steps"] == 12 and fn.keywords["cfg_scale_speaker"] == 8.0 and fn.keywords["sequence_length"] == 640
     out = H.synthesize({"text": "   "}, None, None, None)
     assert out["error_type"] == "ValueError"
+
+
+def _build_c_caller(tmp_path):
+    """gcc -std=c11 on tests/c_abi/abi_smoke.c against include/echo_hip.h + libechohip.so (the header must be plain C)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not available")
+    libdir = os.path.join(ROOT, "echo-tts_amd")
+    exe = str(tmp_path / "abi_smoke")
+    cmd = [gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lechohip", "-L", "/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    _build_c_caller(tmp_path)
