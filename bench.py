@@ -49,17 +49,20 @@ AUDIO_S = S * 2048 / 44100.0
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def dit_gemm_flops(batch: int = 1) -> float:
+PEAK_FP8_TFLOPS = 5000.0           # dense block-scaled fp8 MFMA (same guide): the --c5 line is priced against this
+
+
+def dit_gemm_flops(batch: int = 1, steps: int = STEPS) -> float:
     """Algorithmic FLOPs of the gemm_nt launches inside one sampler run: 80 row-forwards of
     S * 2 743 730 176 plus the one-time modulation tables (cond MLP + 144 low-rank refinements for 40 timesteps)."""
     D, F, Lz, L, R, E = 2048, 5888, 80, 24, 256, 512
     per_row = S * (2 * L * (5 * D * D + 3 * D * F) + 2 * 2 * Lz * D)
-    rows = 20 * 3 + 20
-    mod = 2 * STEPS * (E * D + D * D + D * 3 * D) + 2 * STEPS * (2 * L * 3) * (2 * D * R)
+    rows = (steps // 2) * 3 + (steps - steps // 2)
+    mod = 2 * steps * (E * D + D * D + D * 3 * D) + 2 * steps * (2 * L * 3) * (2 * D * R)
     return float(batch * rows * per_row + mod)
 
 
-def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1):
+def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, fp8: bool = False):
     import echo_tts_amd as E
     from echo_tts_amd import parallel as P
     from echo_tts_amd.weights import dac_param_shapes, dit_param_shapes, random_dac_state, random_dit_state
@@ -68,7 +71,7 @@ def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1):
     sd = random_dit_state(cfg, device, torch.bfloat16, seed=0) if rank == 0 else None
     sd = P.broadcast_state(dit_param_shapes(cfg, with_blockwise=False), sd, device, torch.bfloat16)
     # one engine context (packed weights + KV caches + workspaces) per concurrent request slot
-    models = [E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device) for _ in range(concurrency)]
+    models = [E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device, fp8=fp8) for _ in range(concurrency)]
     del sd
     dsd = random_dac_state(dcfg, device, seed=0) if rank == 0 else None
     dsd = P.broadcast_state(dac_param_shapes(dcfg), dsd, device, torch.float32)
@@ -157,6 +160,9 @@ def main() -> None:
                          "`concurrency` utterances")
     ap.add_argument("--batch", type=int, default=8,
                     help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
+    ap.add_argument("--c5", action="store_true",
+                    help="BASELINE config C5 instead of C2: fp8 (e4m3) operands for the EchoDiT block GEMMs, 100 Euler steps "
+                         "(50 CFG x3 rows + 50 x1 row); the JSON line then says dtype fp8 and names C5 in config.workload")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
     args = ap.parse_args()
@@ -173,7 +179,9 @@ def main() -> None:
     torch.cuda.set_device(device)
     conc = max(1, args.concurrency)
     nb = max(1, args.batch)
-    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc, nb)
+    n_steps = 100 if args.c5 else STEPS
+    sampler_kw = dict(SAMPLER, num_steps=n_steps)
+    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc, nb, fp8=args.c5)
     model, dac = models[0], dacs[0]
     streams = [torch.cuda.Stream(device=device) for _ in range(conc)] if conc > 1 else [torch.cuda.current_stream(device)]
 
@@ -184,7 +192,7 @@ def main() -> None:
         wavs = []
         for c in range(conc):
             with torch.cuda.stream(streams[c]):
-                lat = E.sample_euler_cfg_independent_guidances(models[c], spk, smask, ids, tmask, rng_seed=seed * conc + c, **SAMPLER)
+                lat = E.sample_euler_cfg_independent_guidances(models[c], spk, smask, ids, tmask, rng_seed=seed * conc + c, **sampler_kw)
                 last["latent"] = lat
                 wavs.append(E.ae_decode(dacs[c], pca, lat))
         return wavs[-1]
@@ -216,21 +224,24 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         # live HIP-event timing of every gemm_nt launch of one sampler run (events on the launch stream)
         model.set_profiling(True)
-        lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=7, **SAMPLER)
+        lat = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids, tmask, rng_seed=7, **sampler_kw)
         pr = model.get_profile()
         model.set_profiling(False)
-        flops = dit_gemm_flops(nb)
+        flops = dit_gemm_flops(nb, n_steps)
+        peak = PEAK_FP8_TFLOPS if args.c5 else PEAK_BF16_TFLOPS
         ach_all = flops / (pr.ms_gemm_sum * 1e-3) / 1e12
         # dominant kernel: the gemm_pp_kernel launches of that call (engine-side HIP events on the launch stream)
         ach = pr.flops_pp / (pr.ms_pp_sum * 1e-3) / 1e12 if pr.n_pp else 0.0
         traffic, traffic_src = None, None
         try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected inside this process)
+            if args.c5:
+                raise RuntimeError("the PMC passes were taken on the C2 command")
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
             traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm.json (2 x FETCH_SIZE + WRITE_SIZE, KiB; rocprofv3 --pmc passes of this command at the default batch)"
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (bf16 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
-                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (" + ("fp8-e4m3" if args.c5 else "bf16") + " 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
+                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches": pr.n_pp, "avg_launch_us": round(1e3 * pr.ms_pp_sum / max(pr.n_pp, 1), 2),
                     "flops_per_launch": pr.flops_pp / max(pr.n_pp, 1),
@@ -241,7 +252,7 @@ def main() -> None:
         dp = dac.get_profile()
         dac.set_profiling(False)
         # joint attention inside the sampler call: algorithmic FLOPs of SURVEY.md 8d (14.57 TFLOP per utterance at C2)
-        attn_flops = nb * 640 * 196608.0 * 115760.0
+        attn_flops = nb * 640 * 196608.0 * 115760.0 * (n_steps / STEPS)
         attn = {"ms": round(pr.ms_attn_sum, 2), "launches": pr.n_attn,
                 "achieved_tflops": round(attn_flops / (pr.ms_attn_sum * 1e-3) / 1e12, 1) if pr.n_attn else None}
         phases = {"utterances_per_call": nb, "sampler_ms": round(pr.ms_total, 2), "attention": attn, "sampler_gemm_ms": round(pr.ms_gemm_sum, 2), "mod_tables_ms": round(pr.ms_mod, 2),
@@ -254,7 +265,7 @@ def main() -> None:
         for i in range(4):
             torch.cuda.synchronize()
             t0s = time.perf_counter()
-            lat1 = E.sample_euler_cfg_independent_guidances(model, s1, m1, i1, t1, rng_seed=50 + i, **SAMPLER)
+            lat1 = E.sample_euler_cfg_independent_guidances(model, s1, m1, i1, t1, rng_seed=50 + i, **sampler_kw)
             E.ae_decode(dac, pca, lat1)
             torch.cuda.synchronize()
             ms.append(1e3 * (time.perf_counter() - t0s))
@@ -271,11 +282,13 @@ def main() -> None:
             "metric": "audio-sec/sec/GPU @ seq_len=640, 40 steps, CFG(text=3, spk=8); 1/2/4/8 GPU",
             "value": round(total_audio / dt, 3), "unit": "audio-s/s (whole job; divide by n_gpus for per-GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8 (e4m3 operands of the EchoDiT block GEMMs, fp32 accumulate; bf16 elsewhere, fp32 DAC)" if args.c5 else "bf16", "data": "synthetic",
             "per_gpu": round(total_audio / dt / world, 3),
-            "config": {"workload": f"C2: {conc * nb} utterance(s)/step/GPU ({nb} per sampler call, {conc} HIP stream(s)), seq_len=640, 40 Euler steps (20 CFG x3 rows + 20 x1 row), "
+            "config": {"workload": f"{'C5' if args.c5 else 'C2'}: {conc * nb} utterance(s)/step/GPU ({nb} per sampler call, {conc} HIP stream(s)), seq_len=640, "
+                                   f"{n_steps} Euler steps ({n_steps // 2} CFG x3 rows + {n_steps - n_steps // 2} x1 row), "
                                    "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
-                                   "EchoDiT bf16 + Fish S1-DAC decode fp32, random weights",
+                                   + ("EchoDiT fp8-e4m3 block GEMMs" if args.c5 else "EchoDiT bf16") + " + Fish S1-DAC decode fp32, random weights",
                        "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
             "roofline": roofline, "cpu_baseline": cpu, "single_request": single, "phases": phases,
         }

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -38,6 +38,7 @@ class EchoConfig(C.Structure):
         ("dac_enc_dim", C.c_int), ("dac_enc_n_rates", C.c_int), ("dac_enc_rates", C.c_int * 8), ("dac_enc_tlayers", C.c_int * 8),
         ("dac_enc_window", C.c_int),
         ("dac_n_codebooks", C.c_int), ("dac_codebook_size", C.c_int), ("dac_codebook_dim", C.c_int), ("dac_semantic_size", C.c_int),
+        ("dit_fp8", C.c_int),
     ]
 
 
@@ -67,7 +68,8 @@ class EchoGemmDesc(C.Structure):
                 ("res", vp), ("ldres", c_i64), ("res_bo", c_i64), ("res_bi", c_i64),
                 ("snake_alpha", vp),
                 ("store_main", C.c_int), ("swiglu", C.c_int),
-                ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int)]
+                ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int),
+                ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp)]
 
 
 class EchoAttnSeg(C.Structure):
@@ -116,6 +118,7 @@ SIGNATURES = {
     "echo_dac_encode": (C.c_int, [vp, vp, C.c_long, vp, vp, vp, vp]),
     "echo_set_pca_encode": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, vp]),
     "echo_op_gemm": (C.c_int, [C.c_int, C.POINTER(EchoGemmDesc), vp]),
+    "echo_op_quant_rows_fp8": (C.c_int, [vp, c_i64, vp, c_i64, vp, C.c_int, C.c_int, vp]),
     "echo_op_pack_rows": (C.c_int, [vp, C.c_int, c_i64, vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_op_attention_bf16": (C.c_int, [C.POINTER(EchoAttnDesc), vp]),
     "echo_op_norm": (C.c_int, [C.c_int, C.c_int, vp, c_i64, vp, c_i64, C.c_int, C.c_int, C.c_float, vp, vp, vp]),

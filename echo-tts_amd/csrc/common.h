@@ -23,6 +23,8 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define ECHO_OK 0
@@ -124,6 +126,9 @@ struct GemmArgs {
   float qk_eps;
   const void* qk_w; const void* rope;
   void* vt; long vt_ld, vt_row_stride;
+  // fp8 operands (gemm_pp_kernel only, activations/outputs stay bf16): A and W hold OCP e4m3 bytes, one fp32 scale per A row
+  // and per W row; y = acc * a_scale[m] * w_scale[n] before the tail.  K is then a multiple of 128.
+  int fp8; const float* a_scale; const float* w_scale;
 };
 int gemm_tile_m(int cfg);
 int gemm_num_cfgs();
@@ -169,6 +174,8 @@ hipError_t launch_headnorm_rope_nt(T* x, long ldx, long t_stride, int nt, int ro
                                    hipStream_t st);
 template <typename T> hipError_t launch_embedding(const int* ids, const T* table, T* out, long ldo, int n, int D, hipStream_t st);
 template <typename T> hipError_t launch_silu(const T* x, T* y, long n, hipStream_t st);
+// bf16 rows -> OCP e4m3 bytes + per-row fp32 scale (amax / 448)
+hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st);
 template <typename T> hipError_t launch_scale_inplace(T* x, long n, float s, hipStream_t st);
 template <typename T> hipError_t launch_scale_2d(T* x, long ld, int rows, int cols, float s, hipStream_t st);
 template <typename T> hipError_t launch_mod_finalize(T* mod, long rows, int D, hipStream_t st);

@@ -304,6 +304,42 @@ __global__ void convert_any_kernel(const void* __restrict__ src, int sdt, void* 
 
 inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+// bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (the A / W operands of the fp8 ping-pong GEMM): one wave per row,
+// scale = amax / 448 (1 for an all-zero row), q = e4m3(x * (448 / amax)), round-to-nearest-even by v_cvt_pk_fp8_f32.  The row is
+// read twice (the second pass hits L2); 8 elements per lane and step: 16 bytes in, 8 bytes out.  K % 8 == 0.
+__global__ void __launch_bounds__(256) quant_rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                             float* __restrict__ scale, int rows, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16_t* xr = x + (long)row * ldx;
+  const int nchunk = K >> 3;
+  float amax = 0.0f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const uint4 v = *(const uint4*)(xr + 8 * c);
+    float f[8];
+    Vec4<bf16_t>::unpack(uint2{v.x, v.y}, f);
+    Vec4<bf16_t>::unpack(uint2{v.z, v.w}, f + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+  }
+  amax = wave_max(amax);
+  const bool nz = amax > 0.0f;
+  const float inv = nz ? __fdiv_rn(448.0f, amax) : 1.0f;      // correctly rounded: the operands are reproducible on any host
+  if (lane == 0) scale[row] = nz ? __fdiv_rn(amax, 448.0f) : 1.0f;
+  uint8_t* qr = q + (long)row * ldq;
+  for (int c = lane; c < nchunk; c += 64) {
+    const uint4 v = *(const uint4*)(xr + 8 * c);
+    float f[8];
+    Vec4<bf16_t>::unpack(uint2{v.x, v.y}, f);
+    Vec4<bf16_t>::unpack(uint2{v.z, v.w}, f + 4);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+    *(uint2*)(qr + 8 * c) = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+
 }  // namespace
 
 template <typename T>
@@ -398,6 +434,12 @@ hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch,
   const long total = (long)rows_per_batch * nbatch;
   hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, s, ld, rows_per_batch, total, ncols,
                      ncols_pad, bias, bias_batch_stride, heads_per_bias_row < 1 ? 1 : heads_per_bias_row, causal, window);
+  return hipGetLastError();
+}
+hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st) {
+  if (rows < 1 || K < 8 || (K & 7) || (ldx & 7) || (ldq & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale,
+                     rows, K);
   return hipGetLastError();
 }
 hipError_t launch_mask_to_bias(const uint8_t* mask, float* bias, long n, hipStream_t st) {

@@ -236,6 +236,31 @@ struct Engine : EngineBase {
   }
   int device_key() { int d = 0; (void)hipGetDevice(&d); return d; }
   DevBuf b_gemm_ws, b_tune_c, b_flush;
+  // ------------------------------------------------------------------ fp8 operands (config dit_fp8, bf16 engine; BASELINE C5)
+  bool fp8 = false;
+  std::vector<uint8_t*> q_wqkvg, q_wo, q_w13, q_w2;     // e4m3 copies of the packed block weights
+  std::vector<float*> s_wqkvg, s_wo, s_w13, s_w2;       // one scale per weight row
+  DevBuf b_q8, b_qs;                                    // quantised A operand of the current GEMM + its row scales
+  static bool fp8_shape_ok(long N, long K) { return K % 128 == 0 && N % 8 == 0; }
+  int quant_weight(const T* w, long rows, long K, std::vector<uint8_t*>& qv, std::vector<float*>& sv, hipStream_t st) {
+    uint8_t* q = nullptr; float* sc = nullptr;
+    if (fp8_shape_ok(rows, K)) {
+      CK(alloc_zero((void**)&q, (size_t)rows * K));
+      CK(alloc_zero((void**)&sc, (size_t)rows * sizeof(float)));
+      CK(launch_quant_rows_fp8(w, K, q, K, sc, (int)rows, (int)K, st));
+    }
+    qv.push_back(q); sv.push_back(sc);
+    return ECHO_OK;
+  }
+  // quantises the A rows of `g` (per token row) and points the descriptor at the e4m3 operands; no-op without an fp8 weight
+  int to_fp8(GemmArgs& g, const uint8_t* qw, const float* sw, hipStream_t st) {
+    if (!fp8 || !qw) return ECHO_OK;
+    CK(b_q8.reserve((size_t)(g.M + 256) * g.K));
+    CK(b_qs.reserve((size_t)(g.M + 256) * sizeof(float)));
+    CK(launch_quant_rows_fp8(g.A, g.lda, b_q8.p, g.K, b_qs.as<float>(), g.M, g.K, st));
+    g.A = b_q8.p; g.lda = g.K; g.W = qw; g.ldw = g.K; g.fp8 = 1; g.a_scale = b_qs.as<float>(); g.w_scale = sw;
+    return ECHO_OK;
+  }
   bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : true;
 
   template <typename U>
@@ -319,7 +344,8 @@ struct Engine : EngineBase {
 
   int run(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
-    CKI(plan_gemm<T>(g, st));
+    if (g.fp8) { g.cfg = 5; g.ksplit = 1; }   // e4m3 operands exist for the ping-pong kernel only
+    else CKI(plan_gemm<T>(g, st));
     if (profiling) {
       if (gemm_events_used == gemm_events.size()) {
         hipEvent_t a, b;
@@ -388,6 +414,7 @@ struct Engine : EngineBase {
     const int D = cfg.model_size, L = cfg.num_layers, H = cfg.num_heads, F = cfg.intermediate_size, E = cfg.timestep_embed_size;
     const int R = cfg.adaln_rank;
     if (D / H != 128 || D % 128 || F % 64 || E % KE || R % KE || D % KE) return fail("unsupported EchoDiT sizes (head_dim must be 128)");
+    fp8 = cfg.dit_fp8 != 0 && sizeof(T) == 2;
     if (L * 2 > MAXROWS * 8) return fail("too many layers");
     lat_pad = (int)rup(cfg.latent_size, KE);
     // encoders
@@ -432,6 +459,12 @@ struct Engine : EngineBase {
       CKI(pack(p + ".mlp.w3.weight", c, D, 0, F, D, st, 1));
       CKI(walloc(&dd, D, F)); CKI(pack(p + ".mlp.w2.weight", dd, F, 0, D, F, st));
       wqkvg.push_back(a); wo.push_back(b); w13.push_back(c); w2.push_back(dd);
+      if (fp8) {
+        CKI(quant_weight(a, 4L * D, D, q_wqkvg, s_wqkvg, st));
+        CKI(quant_weight(b, D, D, q_wo, s_wo, st));
+        CKI(quant_weight(c, rup(2 * F, 128), D, q_w13, s_w13, st));
+        CKI(quant_weight(dd, D, F, q_w2, s_w2, st));
+      }
       CKI(pack_vec(p + ".attention.q_norm.weight", qkn + (long)l * 2 * D, D, st));
       CKI(pack_vec(p + ".attention.k_norm.weight", qkn + (long)l * 2 * D + D, D, st));
       for (int w = 0; w < 2; ++w)
@@ -866,6 +899,7 @@ struct Engine : EngineBase {
         GemmArgs g = G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D);
         g.qkv_mode = 1; g.qkv_D = D; g.qkv_S = S; g.rope_heads = H / 2; g.pos0 = start_pos; g.qk_eps = cfg.norm_eps;
         g.qk_w = qkn + (long)l * 2 * D; g.rope = rope; g.vt = vts; g.vt_ld = Sp; g.vt_row_stride = (long)D * Sp;
+        if (fp8) CKI(to_fp8(g, q_wqkvg[l], s_wqkvg[l], st));
         CKI(run(g, st));
       } else {
         CKI(run(G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D), st));
@@ -896,17 +930,20 @@ struct Engine : EngineBase {
       {
         GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
         g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
+        if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st));
         CKI(run(g, st));
       }
       CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, mm + D, mm, st));
       {
         GemmArgs g = G(xn, D, w13[l], D, hh, F, M, 2 * F, D);
         g.swiglu = 1;
+        if (fp8) CKI(to_fp8(g, q_w13[l], s_w13[l], st));
         CKI(run(g, st));
       }
       {
         GemmArgs g = G(hh, F, w2[l], F, x, D, M, D, F);
         g.colscale = mm + 2 * D; g.res = x; g.ldres = D;
+        if (fp8) CKI(to_fp8(g, q_w2[l], s_w2[l], st));
         CKI(run(g, st));
       }
     }
@@ -1622,6 +1659,7 @@ int echo_ctx_create(const echo_config* cfg, int device, echo_ctx** out) {
   if (cfg->precision == ECHO_BF16) c->eng.reset(new Engine<bf16_t>());
   else if (cfg->precision == ECHO_F32) c->eng.reset(new Engine<float>());
   else { delete c; g_create_error = "bad precision"; return ECHO_ERR; }
+  if (cfg->dit_fp8 && cfg->precision != ECHO_BF16) { delete c; g_create_error = "dit_fp8 needs precision ECHO_BF16"; return ECHO_ERR; }
   c->eng->cfg = *cfg;
   c->eng->device = device;
   *out = c;
@@ -1711,6 +1749,10 @@ static int op_status(hipError_t e) {
   return ECHO_ERR;
 }
 
+int echo_op_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream) {
+  return op_status(launch_quant_rows_fp8(x, ldx, q, ldq, scale, rows, K, (hipStream_t)stream));
+}
+
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   GemmArgs g;
   gemm_args_init(&g);
@@ -1723,6 +1765,7 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.colscale = d->colscale; g.res = d->res; g.ldres = d->ldres; g.res_bo = d->res_bo; g.res_bi = d->res_bi;
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
   g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3;
+  g.fp8 = d->fp8; g.a_scale = d->a_scale; g.w_scale = d->w_scale;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
 }
 int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,

@@ -582,11 +582,15 @@ __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, flo
 // (1-4 give wrong results); 5 = correct results + per-wave cycle sums (s_memtime) written to p.ws: {total, K loops,
 // epilogue, tiles} x 8 waves per workgroup; 6 = correct results + per-wave, per-phase cycle sums {load part, wait at
 // barrier 1, MFMA part, wait at barrier 2} x 4 phases; 7 = the epilogue without its global stores (wrong results)
-template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD>
+//
+// FP8: A and W are OCP e4m3 bytes (K-tile = 128 elements = the same 128-byte rows, so staging, ring and phases are unchanged);
+// a phase is 8 v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 FLOPs per cycle) on fragments of 32
+// consecutive K bytes per lane, and the accumulators are multiplied by a_scale[m] * w_scale[n] before the bf16 tails.
+template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = 256, BN = 256, KE = 64, UNIT = 16384, KTILE = 4 * UNIT;
+  constexpr int BM = 256, BN = 256, KE = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, UNIT = 16384, KTILE = 4 * UNIT;
   static_assert(LEAD >= 2 && LEAD <= 6, "see the WAR/RAW rules above");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,11 +635,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         if (j == 0 || j == 3) {                                // A: unit row = wave row (ur >> 5) x 32 rows of this m-half
           int gm = tm * BM + (ur >> 5) * 64 + (j == 3 ? 32 : 0) + (ur & 31);
           gm = gm < p.M ? gm : p.M - 1;
-          voff[j][i] = (unsigned)((long)gm * p.lda * 2 + chunk * 16);
+          voff[j][i] = (unsigned)((long)gm * p.lda * ES + chunk * 16);
         } else {                                               // W: unit row = wave column (ur >> 6) x 64 rows of this n-half
           int gn = tn * BN + (ur >> 6) * 128 + (j == 2 ? 64 : 0) + (ur & 63);
           gn = gn < p.Npad ? gn : p.Npad - 1;
-          voff[j][i] = (unsigned)((long)gn * p.ldw * 2 + chunk * 16);
+          voff[j][i] = (unsigned)((long)gn * p.ldw * ES + chunk * 16);
         }
       }
   };
@@ -643,10 +647,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   // last K-tile of an output tile the stream moves on to the next tile of this workgroup; after the last tile the
   // cursors stop, so the look-ahead units of the final phases re-stage the last K-tile into ring slots nobody reads
   // again: every phase issues exactly two DMAs per wave and the counted vmcnt holds to the end.
-  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * 2;
+  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * ES;
   const int kb0 = it0 % kb_per_tap;
-  const char* const a_start = (const char*)p.A + ((long)p.tap_base * p.lda + a_z + (long)(it0 / kb_per_tap) * p.tap_shift * p.lda) * 2 + (long)kb0 * KBYTES;
-  const char* const w_start = (const char*)p.W + w_z * 2 + (long)it0 * KBYTES;
+  const char* const a_start = (const char*)p.A + ((long)p.tap_base * p.lda + a_z + (long)(it0 / kb_per_tap) * p.tap_shift * p.lda) * ES + (long)kb0 * KBYTES;
+  const char* const w_start = (const char*)p.W + w_z * ES + (long)it0 * KBYTES;
   const char* a_cur = a_start;
   const char* w_cur = w_start;
   int kb = kb0, kt_staged = 0, v_stage = blockIdx.x;
@@ -689,12 +693,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   // ---- fragment read addresses: lane (r = lane & 15, g = lane >> 4) reads row r of a 16-row fragment, k-chunk g (+ 4)
   const int wm = wid >> 1, wn = wid & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  const int c0 = ((fg ^ (fr >> 1)) & 7) << 4;                 // swizzled 16-byte chunk of k-half 0; k-half 1 is c0 ^ 64
-  const int a_rd0 = (wm * 32 + fr) * KBYTES + c0, a_rd1 = a_rd0 ^ 64;   // + unit j0 / j3, + 16 i rows
-  const int w_rd0 = (wn * 64 + fr) * KBYTES + c0, w_rd1 = w_rd0 ^ 64;   // + unit j1 / j2, + 16 jn rows
+  // bf16: swizzled 16-byte chunk fg of k-half 0, k-half 1 is c0 ^ 64.  fp8: the lane's 32 K bytes are chunks 2 fg, 2 fg + 1
+  const int c0 = (((FP8 ? 2 * fg : fg) ^ (fr >> 1)) & 7) << 4;
+  constexpr int C1X = FP8 ? 16 : 64;
+  const int a_rd0 = (wm * 32 + fr) * KBYTES + c0, a_rd1 = a_rd0 ^ C1X;   // + unit j0 / j3, + 16 i rows
+  const int w_rd0 = (wn * 64 + fr) * KBYTES + c0, w_rd1 = w_rd0 ^ C1X;   // + unit j1 / j2, + 16 jn rows
 
   f32x4 acc[4][8];                 // [m fragment][n fragment]: lane holds C[m = 16 i + fr][n = 16 jn + 4 fg + r]
-  bf16x8 af[2][2], wf[2][4][2];    // A (i, k-half) of the current m-half; W (n-half, jn, k-half)
+  bf16x8 af[2][2], wf[2][4][2];    // A (i, k-half) of the current m-half; W (n-half, jn, k-half); fp8: (.., 16-byte half of the 32 K bytes)
 
   // ---- prologue: the first LEAD units; units 0 and 1 must have landed everywhere before phase 0 reads them
 #pragma unroll
@@ -762,6 +768,19 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
 #pragma unroll
       for (int jn = 0; jn < 4; ++jn) asm volatile("" :: "v"(wf[nh][jn][0]), "v"(wf[nh][jn][1]));
     } else
+    if constexpr (FP8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, af[i][0]), __builtin_bit_cast(i32x4, af[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+          const i32x8 w8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wf[nh][jn][0]), __builtin_bit_cast(i32x4, wf[nh][jn][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0 in every byte (the row scales are applied in the epilogue)
+          acc[2 * mh + i][4 * nh + jn] =
+              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[2 * mh + i][4 * nh + jn], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      }
+    } else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -827,6 +846,21 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
 
     const int m_base = tile_m * BM + wm * 64;      // + 16 i + row
     const int n_base = tile_n * BN + wn * 128;     // + 64 h + 8 c8 (W-row index of the accumulator columns)
+    if constexpr (FP8) {
+      // dequantise in the accumulator layout: lane holds C[m_base + 16 i + fr][n_base + 16 jn + 4 fg + r]
+      float sa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr; sa[i] = p.a_scale[m < p.M ? m : p.M - 1]; }
+#pragma unroll
+      for (int jn = 0; jn < 8; ++jn) {
+        const int n0 = n_base + 16 * jn + 4 * fg;
+        const f32x4 sw = *(const f32x4*)(p.w_scale + (n0 + 3 < p.Npad ? n0 : p.Npad - 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][jn][r] *= sa[i] * sw[r];
+      }
+    }
     if constexpr (DIAG == 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1116,13 +1150,13 @@ int pp_num_cus() {
   return n;
 }
 
-template <bool SW, int DIAG = 0, int LEAD = PP_LEAD>
+template <bool SW, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false>
 hipError_t launch_pp(const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   static const int env_gn = getenv("ECHO_PP_GN") ? atoi(getenv("ECHO_PP_GN")) : 0;
   if (g.pp_gn <= 0 && env_gn > 0) g.pp_gn = env_gn;
   static std::atomic<unsigned long long> prepared{0};
-  auto kern = gemm_pp_kernel<SW, DIAG, LEAD>;
+  auto kern = gemm_pp_kernel<SW, DIAG, LEAD, FP8>;
   constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
   if (hipError_t e = ensure_dyn_lds((const void*)kern, SMEM, prepared); e != hipSuccess) return e;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.Npad + 255) / 256;
@@ -1174,9 +1208,15 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
         (g.qkv_mode && ((g.qkv_D & 255) || (g.vt_ld & 7))))
       return hipErrorInvalidValue;
   }
+  if (g.fp8 && g.cfg != 5) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel only
   if (g.cfg == 5) {
-    if constexpr (Num<T>::is_bf16) return launch_pp<SW>(g, st);
-    else return hipErrorInvalidValue;   // the ping-pong kernel is bf16 only
+    if constexpr (Num<T>::is_bf16) {
+      if (g.fp8) {
+        if (!g.a_scale || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
+        return launch_pp<SW, 0, PP_LEAD, true>(g, st);
+      }
+      return launch_pp<SW>(g, st);
+    } else return hipErrorInvalidValue;   // the ping-pong kernel is bf16 only
   }
   if (g.cfg >= 100) {   // timing experiments (tools/bench_gemm.py --diag): wrong results by construction
     if constexpr (Num<T>::is_bf16 && !SW) {

@@ -359,7 +359,7 @@ def sample_pipeline_chunked(
 
 # --------------------------------------------------------------------------- loading from LOCAL files
 def load_model_from_path(path: str, device: str = "cuda", dtype: torch.dtype | None = torch.bfloat16,
-                         delete_blockwise_modules: bool = False, config=None) -> EchoDiT:
+                         delete_blockwise_modules: bool = False, config=None, fp8: bool = False) -> EchoDiT:
     """Local-file counterpart of load_model_from_hf (reference inference.py:14-47): same safetensors key layout."""
     import safetensors.torch as st
     from .model import EchoDiTConfig
@@ -367,7 +367,8 @@ def load_model_from_path(path: str, device: str = "cuda", dtype: torch.dtype | N
     if delete_blockwise_modules:
         state = {k: v for k, v in state.items() if not (k.startswith("latent_encoder.") or k.startswith("latent_norm")
                                                         or ".wk_latent" in k or ".wv_latent" in k)}
-    return EchoDiT(config or EchoDiTConfig(), state, dtype=dtype or torch.bfloat16, device="cuda:0" if device == "cuda" else device)
+    return EchoDiT(config or EchoDiTConfig(), state, dtype=dtype or torch.bfloat16, device="cuda:0" if device == "cuda" else device,
+                   fp8=fp8)
 
 
 def load_fish_ae_from_path(path: str, device: str = "cuda", dtype: torch.dtype | None = torch.float32, config=None) -> DAC:

@@ -102,8 +102,11 @@ class EchoDiT:
     MAX_POS = 4096
 
     def __init__(self, config, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
-                 device: str | torch.device = "cuda:0"):
+                 device: str | torch.device = "cuda:0", fp8: bool = False):
+        """`fp8=True` (BASELINE config C5; bf16 engine only): the four large linears of every block run on e4m3 operands
+        (weights quantised once per output row, activations per token row) at twice the bf16 MFMA rate."""
         self.config = EchoDiTConfig.from_any(config)
+        self.fp8 = bool(fp8)
         self._dtype = dtype
         self._device = torch.device(device)
         if self._device.type != "cuda":
@@ -115,6 +118,7 @@ class EchoDiT:
         for f in fields(EchoDiTConfig):
             setattr(cfg, f.name, getattr(self.config, f.name))
         cfg.has_latent_encoder = int(has_latent)
+        cfg.dit_fp8 = int(self.fp8)
         self.has_latent_encoder = has_latent
         ctx = C.c_void_p()
         L.check(self._lib.echo_ctx_create(C.byref(cfg), self._device.index or 0, C.byref(ctx)))

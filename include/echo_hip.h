@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 2
+#define ECHO_ABI_VERSION 3
 
 typedef struct echo_ctx echo_ctx;
 
@@ -49,6 +49,11 @@ typedef struct {
    * dac_enc_dim == 0: no encode path in this context. */
   int dac_enc_dim, dac_enc_n_rates, dac_enc_rates[8], dac_enc_tlayers[8], dac_enc_window;
   int dac_n_codebooks, dac_codebook_size, dac_codebook_dim, dac_semantic_size;
+  /* BASELINE config C5 ("fp8 MFMA weight path for DiT GEMMs"): 1 = the four large linears of every EchoDiT block (QKV+gate,
+   * wo, w1|w3, w2) run on OCP e4m3 operands — weights quantised once at echo_finalize_dit with one scale per output row,
+   * activations per token row in front of each GEMM — on the block-scaled MFMA at twice the bf16 rate; accumulation, tails,
+   * attention, norms and the encoders stay as in the bf16 engine.  precision must be ECHO_BF16. */
+  int dit_fp8;
 } echo_config;
 
 int echo_abi_version(void);
@@ -150,8 +155,12 @@ typedef struct {
   int cfg;                       /* plan: 0..4, 6..9 tile configurations (csrc/gemm.hip TileCfg table), 5 = bf16 ping-pong kernel */
   int ksplit; void* ws; int64_t ws_bytes;   /* split-K: fp32 workspace of ksplit * roundup(M,768) * Npad * 4 bytes */
   int split3;                    /* fp32 only: 3 x bf16 MFMA per product (hi/lo operand splitting), ~1e-5 relative error */
+  int fp8;                       /* dtype ECHO_BF16, cfg 5 only: A and W are e4m3 bytes, y = acc * a_scale[m] * w_scale[n]; K % 128 == 0 */
+  const float* a_scale; const float* w_scale;
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
+/* bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (amax / 448): the operand format of the fp8 GEMM */
+int echo_op_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream);
 int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,
                       int cols, int dst_row0, int swiglu_half, void* stream);
 

@@ -38,7 +38,7 @@ def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
 def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
          nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
          vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
-         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None):
+         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None):
     d = L.EchoGemmDesc()
     es = A.element_size()
     d.A = A.data_ptr() + a_offset_elems * es
@@ -57,13 +57,15 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     d.snake_alpha = ptr(snake_alpha)
     d.store_main, d.swiglu = store_main, swiglu
     d.cfg, d.ksplit, d.split3 = cfg, ksplit, split3
+    if a_scale is not None:   # e4m3 operands: A / W are uint8 tensors, the output C decides the dtype code
+        d.fp8, d.a_scale, d.w_scale = 1, a_scale.data_ptr(), w_scale.data_ptr()
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     elif ksplit > 1:
         need = ksplit * ((M + 767) // 768 * 768) * d.Npad * 4   # rows padded for every tile height (128 / 256 / 384)
         ws = torch.empty((need,), dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = ws.data_ptr(), need
-    L.check(lib().echo_op_gemm(code(A), C.byref(d), stream()))
+    L.check(lib().echo_op_gemm(code(C_out if a_scale is not None else A), C.byref(d), stream()))
 
 
 def pack_swiglu(w1: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
@@ -89,3 +91,12 @@ def bf16_close(out: torch.Tensor, ref: torch.Tensor, ulps: float = 2.0, atol: fl
 
 def rms(x: torch.Tensor) -> float:
     return float(x.float().pow(2).mean().sqrt())
+
+
+def quant_rows_fp8(x: torch.Tensor):
+    """bf16 (rows, K) -> (uint8 e4m3 bytes (rows, K), fp32 scale (rows,)) through echo_op_quant_rows_fp8."""
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    L.check(lib().echo_op_quant_rows_fp8(x.data_ptr(), x.stride(0), q.data_ptr(), K, s.data_ptr(), rows, K, stream()))
+    return q, s

@@ -454,6 +454,41 @@ def test_fp8_weight_numerics_c5(golden, tiny_models):
     assert bool(torch.isfinite(b).all()) and 0.0 < e < 0.5 * U.rms(a)
 
 
+def test_fp8_mfma_engine_c5(golden, tiny_models):
+    """BASELINE config C5 on the real fp8 path (EchoDiT(fp8=True): e4m3 weights per output row + e4m3 activations per token
+    row on the block-scaled MFMA): 100 Euler steps on the tiny model and one forward at full width, distance to the bf16
+    engine reported and sanity-bounded (no tolerance is promised for fp8); deterministic."""
+    g, tag = golden, "tiny"
+    w = {k: v.bfloat16() for k, v in R.make_dit_weights(TINY, seed=0).items()}
+    m8 = E.EchoDiT(TINY, w, dtype=torch.bfloat16, device=DEV, fp8=True)
+    kw = dict(SAMPLER_CASES["cfg_default"], num_steps=100)
+    args = (g[f"{tag}.spk"], g[f"{tag}.smask"].bool(), g[f"{tag}.ids"], g[f"{tag}.tmask"].bool())
+    a = E.sample_euler_cfg_independent_guidances(tiny_models["bf16"], *args, rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"], **kw)
+    b = E.sample_euler_cfg_independent_guidances(m8, *args, rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"], **kw)
+    b2 = E.sample_euler_cfg_independent_guidances(m8, *args, rng_seed=0, sequence_length=32, x_init=g[f"{tag}.x0"], **kw)
+    e = rms(a, b)
+    print(f"C5 (tiny, 100 steps): fp8 MFMA path vs bf16 engine: latent rms distance {e:.3e} (latent rms {U.rms(a):.3f})")
+    assert torch.equal(b, b2)
+    assert bool(torch.isfinite(b).all()) and 0.0 < e < 0.5 * U.rms(a)
+    with pytest.raises(RuntimeError, match="dit_fp8 needs precision"):
+        E.EchoDiT(TINY, {k: v.float() for k, v in w.items()}, dtype=torch.float32, device=DEV, fp8=True)
+    # full width, one layer of each stack: a single velocity prediction
+    ww = {k: v.bfloat16() for k, v in R.make_dit_weights(WIDE1, seed=0).items()}
+    mb, mf = E.EchoDiT(WIDE1, ww, dtype=torch.bfloat16, device=DEV), E.EchoDiT(WIDE1, ww, dtype=torch.bfloat16, device=DEV, fp8=True)
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 256, (1, 40), generator=gen, dtype=torch.int32)
+    tmask = torch.ones((1, 40), dtype=torch.bool)
+    spk, smask = torch.randn((1, 64, 80), generator=gen), torch.ones((1, 64), dtype=torch.bool)
+    x = torch.randn((1, 200, 80), generator=gen)
+    outs = []
+    for m in (mb, mf):
+        kvt, kvs = m.get_kv_cache_text(ids, tmask), m.get_kv_cache_speaker(spk, smask)
+        outs.append(m(x, torch.full((1,), 0.6), tmask, smask, kvt, kvs).float().cpu())
+    rel = rms(outs[0], outs[1]) / U.rms(outs[0])
+    print(f"C5 (full width, 1 layer): fp8 forward vs bf16 forward: relative rms {rel:.3e}")
+    assert rel < 0.1, rel
+
+
 def test_voice_cloning_pipeline_from_audio(golden, tiny_models):
     """The whole reference flow of handler.py:750-758 on the tiny models, starting from speaker AUDIO: DAC encode ->
     get_speaker_latent_and_mask -> sampler -> ae_decode -> crop, against the oracle run stage by stage on the same inputs."""

@@ -448,3 +448,88 @@ def test_plain_c_caller_runs_through_the_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "abi_smoke: ok" in r.stdout
+
+
+def _deq(q8: torch.Tensor) -> torch.Tensor:
+    """uint8 e4m3 bytes -> fp32 values (decoded on the CPU: no dependence on the GPU build's float8 kernels)."""
+    return q8.cpu().view(torch.float8_e4m3fn).float().to(q8.device)
+
+
+def _to_e4m3_bytes(x: torch.Tensor) -> torch.Tensor:
+    return x.float().cpu().to(torch.float8_e4m3fn).view(torch.uint8).to(x.device)
+
+
+def _quant_ref(x: torch.Tensor):
+    """The kernel's arithmetic in torch: scale = amax / 448, q = e4m3(x * (448 / amax)) (fp32 ops, round to nearest even)."""
+    xf = x.float().cpu()                                  # IEEE fp32 division on the host = __fdiv_rn in the kernel
+    amax = xf.abs().amax(dim=1, keepdim=True)
+    nz = amax > 0
+    inv = torch.where(nz, 448.0 / amax, torch.ones_like(amax))
+    sc = torch.where(nz, amax / 448.0, torch.ones_like(amax))
+    return _to_e4m3_bytes(xf * inv).to(x.device), sc[:, 0].to(x.device)
+
+
+def test_quant_rows_fp8_matches_torch_e4m3():
+    x = rnd(300, 2048, dtype=torch.bfloat16)
+    x[7] = 0                                             # an all-zero row keeps scale 1
+    x[11, 5] = 37.5                                      # an outlier sets its row's scale
+    q, s = U.quant_rows_fp8(x)
+    q_ref, s_ref = _quant_ref(x)
+    assert torch.equal(s, s_ref)
+    # v_cvt_pk_fp8_f32 resolves NEAR-ties to even (a product a hair above the midpoint of two e4m3 codes goes to the even
+    # one), torch rounds on the full fp32 value: measured 0.05 % of the elements land on the neighbouring code.  Everything
+    # else is bit-identical; -0 / +0 aside.
+    d, dr = _deq(q), _deq(q_ref)
+    bad = d != dr
+    assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
+    step = dr.abs().clamp_min(2.0 ** -6) * 0.126            # one e4m3 step is 1/8 of the power of two below |value|
+    assert bool(((d - dr).abs()[bad] <= step[bad] * 1.0001).all())
+    scaled = (x.float() * (448.0 / x.float().abs().amax(dim=1, keepdim=True).clamp_min(1e-30)))
+    mid = 0.5 * (d + dr)
+    assert bool(((scaled - mid).abs()[bad] <= 2.0 ** -9 * mid.abs()[bad]).all())   # only products at a rounding boundary differ
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 512), (1000, 640, 2048), (2560, 2048, 5888)])
+def test_gemm_pingpong_fp8_matches_dequantised_product(M, N, K):
+    """gemm_pp_kernel<FP8>: C = bf16((A8 . W8^T) * a_scale[m] * w_scale[n]) against the fp32 product of the dequantised
+    operands (every e4m3 x e4m3 product is exact in fp32; only the summation order differs)."""
+    A, W = rnd(M, K, dtype=torch.bfloat16), U.pad_rows(rnd(N, K, dtype=torch.bfloat16, seed=1))
+    A8, sa = U.quant_rows_fp8(A)
+    W8, sw = U.quant_rows_fp8(W)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    U.gemm(A8, W8, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, cfg=5, a_scale=sa, w_scale=sw)
+    ref = (_deq(A8) @ _deq(W8)[:N].T) * sa[:, None] * sw[None, :N]
+    # the block-scaled MFMA does not add its 128 products in an fp32 chain: deviations of up to ~1e-4 of the output rms were
+    # measured on outputs that cancel to ~0 (invisible after the bf16 rounding of any output of ordinary size)
+    U.bf16_close(out, ref.bfloat16(), ulps=2.0, atol=5e-4 * float(ref.pow(2).mean().sqrt()) + 2e-3)
+    # and close to the unquantised bf16 product: two e4m3 roundings per product, ~3 % relative rms
+    exact = A.float() @ W[:N].float().T
+    rel = ((out.float() - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()).item()
+    assert rel < 0.06, rel
+
+
+def test_gemm_pingpong_fp8_exact_on_integers_and_swiglu():
+    """Small integers are exact in e4m3 and in the fp32 accumulator: bit-exact result at a sampler-sized shape (guards the
+    fragment addressing of the 32-byte K runs and the LDS ring), plus the SwiGLU register tail on fp8 operands."""
+    M, N, K = 1920, 2048, 2048
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(DEV, torch.float32)
+    W = torch.randint(-3, 4, (N, K), generator=g).to(DEV, torch.float32)
+    A8, W8 = _to_e4m3_bytes(A), _to_e4m3_bytes(W)
+    ones_m, ones_n = torch.ones(M, device=DEV), torch.ones(N, device=DEV)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    U.gemm(A8, W8, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, cfg=5, a_scale=ones_m, w_scale=ones_n)
+    assert torch.equal(out, (A @ W.T).bfloat16())
+    F, K2, M2 = 192, 512, 300
+    a = rnd(M2, K2, dtype=torch.bfloat16)
+    w1, w3 = rnd(F, K2, dtype=torch.bfloat16, seed=5, scale=0.1), rnd(F, K2, dtype=torch.bfloat16, seed=6, scale=0.1)
+    Wp = U.pack_swiglu(w1, w3)
+    a8, sa = U.quant_rows_fp8(a)
+    w8, sw = U.quant_rows_fp8(Wp)
+    o2 = torch.zeros((M2, F), dtype=torch.bfloat16, device=DEV)
+    U.gemm(a8, w8, o2, M=M2, N=2 * F, K=K2, lda=K2, ldw=K2, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=5, a_scale=sa, w_scale=sw)
+    full = (_deq(a8) @ _deq(w8).T) * sa[:, None] * sw[None, :]
+    # undo the [16 x w1 | 16 x w3] row packing of pack_swiglu
+    blk = full[:, :2 * F].reshape(M2, F // 16, 2, 16)
+    ya, yb = blk[:, :, 0].reshape(M2, F).bfloat16(), blk[:, :, 1].reshape(M2, F).bfloat16()
+    U.bf16_close(o2, (torch.nn.functional.silu(ya.float()).bfloat16().float() * yb.float()).bfloat16(), ulps=2.0, atol=2e-3)

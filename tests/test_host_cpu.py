@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header():
     # sizes computed from the C declarations (ints / floats / pointers / int64), guarding field drift
     assert ctypes.sizeof(L.EchoStep) == 7 * 4
-    assert ctypes.sizeof(L.EchoConfig) == 4 * (1 + 5 + 1 + 5 + 5 + 2 + 1 + 3 + 8 + 5 + 1 + 4 + 1 + (2 + 8 + 8 + 1) + 4)
+    assert ctypes.sizeof(L.EchoConfig) == 4 * (1 + 5 + 1 + 5 + 5 + 2 + 1 + 3 + 8 + 5 + 1 + 4 + 1 + (2 + 8 + 8 + 1) + 4 + 1)   # ... + dit_fp8
     assert ctypes.sizeof(L.EchoSamplerParams) == 10 * 4 + 2 * 8
 
 
