@@ -176,6 +176,9 @@ template <typename T> hipError_t launch_embedding(const int* ids, const T* table
 template <typename T> hipError_t launch_silu(const T* x, T* y, long n, hipStream_t st);
 // bf16 rows -> OCP e4m3 bytes + per-row fp32 scale (amax / 448)
 hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st);
+// bf16 AdaLN-apply norm (norm_kernel<bf16, NORM_ADALN>) whose output leaves as e4m3 bytes + per-row scale
+hipError_t launch_norm_adaln_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int D, float eps, const void* scale1p,
+                                 const void* shift, hipStream_t st);
 template <typename T> hipError_t launch_scale_inplace(T* x, long n, float s, hipStream_t st);
 template <typename T> hipError_t launch_scale_2d(T* x, long ld, int rows, int cols, float s, hipStream_t st);
 template <typename T> hipError_t launch_mod_finalize(T* mod, long rows, int D, hipStream_t st);

@@ -304,6 +304,64 @@ __global__ void convert_any_kernel(const void* __restrict__ src, int sdt, void* 
 
 inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+// NORM_ADALN fused with the e4m3 row quantisation (fp8 engine): the bf16 value the bf16 engine would have stored is formed in
+// registers, its row maximum sets the scale, and only the e4m3 bytes + the scale leave the CU (1 byte per element instead
+// of 2 written + 2 read back by quant_rows_fp8_kernel).  Same arithmetic as norm_kernel<bf16, NORM_ADALN> + quant_rows_fp8.
+__global__ void __launch_bounds__(256) norm_adaln_fp8_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                             float* __restrict__ scale, int rows, int D, float eps,
+                                                             const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int MAXC = 8;
+  const int nch = D >> 3;
+  float v[MAXC][8];
+  float s2 = 0.f;
+  const bf16_t* xr = x + (long)row * ldx;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      Chunk8<bf16_t>::load(xr + ch * 8, v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += v[c][i] * v[c][i];
+    }
+  }
+  s2 = wave_sum(s2);
+  const float rs = rsqrtf(s2 / (float)D + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float a[8], b[8];
+      Chunk8<bf16_t>::load(w0 + ch * 8, a);
+      Chunk8<bf16_t>::load(w1 + ch * 8, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[c][i] = Num<bf16_t>::rnd(__fadd_rn(__fmul_rn(__fmul_rn(v[c][i], rs), a[i]), b[i]));
+        amax = fmaxf(amax, fabsf(v[c][i]));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  const bool nz = amax > 0.0f;
+  const float inv = nz ? __fdiv_rn(448.0f, amax) : 1.0f;
+  if (lane == 0) scale[row] = nz ? __fdiv_rn(amax, 448.0f) : 1.0f;
+  uint8_t* qr = q + (long)row * ldq;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+      *(uint2*)(qr + ch * 8) = uint2{(unsigned)lo, (unsigned)hi};
+    }
+  }
+}
+
 // bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (the A / W operands of the fp8 ping-pong GEMM): one wave per row,
 // scale = amax / 448 (1 for an all-zero row), q = e4m3(x * (448 / amax)), round-to-nearest-even by v_cvt_pk_fp8_f32.  The row is
 // read twice (the second pass hits L2); 8 elements per lane and step: 16 bytes in, 8 bytes out.  K % 8 == 0.
@@ -434,6 +492,13 @@ hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch,
   const long total = (long)rows_per_batch * nbatch;
   hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, s, ld, rows_per_batch, total, ncols,
                      ncols_pad, bias, bias_batch_stride, heads_per_bias_row < 1 ? 1 : heads_per_bias_row, causal, window);
+  return hipGetLastError();
+}
+hipError_t launch_norm_adaln_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int D, float eps, const void* scale1p,
+                                 const void* shift, hipStream_t st) {
+  if (rows < 1 || D < 8 || (D & 7) || D > 4096 || (ldx & 7) || (ldq & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(norm_adaln_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale,
+                     rows, D, eps, (const bf16_t*)scale1p, (const bf16_t*)shift);
   return hipGetLastError();
 }
 hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st) {

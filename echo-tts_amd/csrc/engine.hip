@@ -253,11 +253,18 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
   // quantises the A rows of `g` (per token row) and points the descriptor at the e4m3 operands; no-op without an fp8 weight
-  int to_fp8(GemmArgs& g, const uint8_t* qw, const float* sw, hipStream_t st) {
+  int fp8_reserve(long M, long K) {
+    CK(b_q8.reserve((size_t)(M + 256) * K));
+    CK(b_qs.reserve((size_t)(M + 256) * sizeof(float)));
+    return ECHO_OK;
+  }
+  // `quantised`: b_q8 / b_qs already hold the A rows (norm_adaln_fp8 wrote them)
+  int to_fp8(GemmArgs& g, const uint8_t* qw, const float* sw, hipStream_t st, bool quantised = false) {
     if (!fp8 || !qw) return ECHO_OK;
-    CK(b_q8.reserve((size_t)(g.M + 256) * g.K));
-    CK(b_qs.reserve((size_t)(g.M + 256) * sizeof(float)));
-    CK(launch_quant_rows_fp8(g.A, g.lda, b_q8.p, g.K, b_qs.as<float>(), g.M, g.K, st));
+    if (!quantised) {
+      CKI(fp8_reserve(g.M, g.K));
+      CK(launch_quant_rows_fp8(g.A, g.lda, b_q8.p, g.K, b_qs.as<float>(), g.M, g.K, st));
+    }
     g.A = b_q8.p; g.lda = g.K; g.W = qw; g.ldw = g.K; g.fp8 = 1; g.a_scale = b_qs.as<float>(); g.w_scale = sw;
     return ECHO_OK;
   }
@@ -893,13 +900,21 @@ struct Engine : EngineBase {
     for (int l = 0; l < L; ++l) {
       const T* ma = modrow + (long)(2 * l) * 3 * D;
       const T* mm = modrow + (long)(2 * l + 1) * 3 * D;
-      CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, ma + D, ma, st));
+      // fp8 engine: the AdaLN output goes straight to e4m3 rows (b_q8 / b_qs) when the following GEMM takes fp8 operands
+      const bool nq1 = fp8 && D % 256 == 0 && q_wqkvg[l] != nullptr && D <= 4096;
+      const bool nq2 = fp8 && q_w13[l] != nullptr && D <= 4096;
+      if (nq1) {
+        CKI(fp8_reserve(M, std::max(D, F)));
+        CK(launch_norm_adaln_fp8(x, D, b_q8.p, D, b_qs.as<float>(), M, D, cfg.norm_eps, ma + D, ma, st));
+      } else {
+        CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, ma + D, ma, st));
+      }
       if (D % 256 == 0) {
         // one launch: projection + q/k head RMSNorm + half-head RoPE + transposed V (gemm.hip fused QKV epilogue)
         GemmArgs g = G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D);
         g.qkv_mode = 1; g.qkv_D = D; g.qkv_S = S; g.rope_heads = H / 2; g.pos0 = start_pos; g.qk_eps = cfg.norm_eps;
         g.qk_w = qkn + (long)l * 2 * D; g.rope = rope; g.vt = vts; g.vt_ld = Sp; g.vt_row_stride = (long)D * Sp;
-        if (fp8) CKI(to_fp8(g, q_wqkvg[l], s_wqkvg[l], st));
+        if (fp8) CKI(to_fp8(g, q_wqkvg[l], s_wqkvg[l], st, nq1));
         CKI(run(g, st));
       } else {
         CKI(run(G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D), st));
@@ -933,11 +948,16 @@ struct Engine : EngineBase {
         if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st));
         CKI(run(g, st));
       }
-      CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, mm + D, mm, st));
+      if (nq2) {
+        CKI(fp8_reserve(M, std::max(D, F)));
+        CK(launch_norm_adaln_fp8(x, D, b_q8.p, D, b_qs.as<float>(), M, D, cfg.norm_eps, mm + D, mm, st));
+      } else {
+        CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, mm + D, mm, st));
+      }
       {
         GemmArgs g = G(xn, D, w13[l], D, hh, F, M, 2 * F, D);
         g.swiglu = 1;
-        if (fp8) CKI(to_fp8(g, q_w13[l], s_w13[l], st));
+        if (fp8) CKI(to_fp8(g, q_w13[l], s_w13[l], st, nq2));
         CKI(run(g, st));
       }
       {
