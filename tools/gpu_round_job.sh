@@ -21,6 +21,10 @@ tail -3 $O/smoke.log
 timeout -k 10 900 python bench.py > $O/bench.log 2> $O/bench.err
 tail -n 1 $O/bench.log > $O/r01_bench_line_$V.json
 tail -c 300 $O/bench.log
+# 3b. BASELINE config C5 (fp8 operands, 100 steps) on the same box
+timeout -k 10 900 python bench.py --c5 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5.log 2> $O/bench_c5.err
+tail -n 1 $O/bench_c5.log > $O/r01_bench_line_c5_$V.json
+head -c 200 $O/r01_bench_line_c5_$V.json; echo
 # 4. kernel trace of the same command (shorter run, no CPU leg)
 timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1
 rm -f $O/prof/*kernel_trace.csv $O/prof/*/*kernel_trace.csv
