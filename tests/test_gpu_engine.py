@@ -438,6 +438,30 @@ def test_batched_call_equals_single_calls_at_full_width(dname, dt, tol):
         assert e < tol * max(1.0, U.rms(one)), (b, e, U.rms(one))
 
 
+def test_handler_batches_the_chunks_of_a_request(golden, tiny_models):
+    """handler.synthesize sends the independent text chunks of a request through ONE sampler call (parameters.max_chunk_batch,
+    default 8) instead of one call per chunk (handler.py:747-759): same seeds, same noise per chunk; on the fp32 engine the
+    result must equal the sequential path within the waveform tolerance."""
+    from echo_tts_amd import handler as H
+    m = tiny_models["f32"]
+    dac = E.DAC(TINY_DAC, R.make_dac_weights(TINY_DAC, 0), device=DEV)
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    text = ("The quick brown fox jumps over the lazy dog near the quiet river bank. " * 3 + "Then it rests for a while under the old oak tree. " * 3).strip()
+    base = dict(SAMPLER_CASES["cfg_default"], sequence_length=32, seed=5, max_chars_per_chunk=90, normalize_boundaries=False, enable_crossfade=False)
+    outs = {}
+    for mb in (1, 8, 2):
+        out = H.synthesize({"text": text, "parameters": dict(base, max_chunk_batch=mb)}, m, dac, st,
+                           speaker_latent=golden["tiny.spk"], speaker_mask=golden["tiny.smask"].bool())
+        assert "error" not in out, out.get("traceback")
+        outs[mb] = out
+    assert outs[1]["chunks"] >= 3 and outs[8]["chunks"] == outs[1]["chunks"]
+    for mb in (8, 2):
+        a, b = outs[1]["audio"].float().cpu(), outs[mb]["audio"].float().cpu()
+        assert a.shape == b.shape, (a.shape, b.shape)
+        assert rms(a, b) <= WAV_TOL, rms(a, b)
+
+
 def test_fp8_weight_numerics_c5(golden, tiny_models):
     """BASELINE config C5 as a parity case: DiT block linears stored as OCP fp8-e4m3 (per-row scale), 100 Euler steps.  No
     tolerance is promised for fp8: the RMS distance to the bf16 engine is reported and only sanity-bounded."""
