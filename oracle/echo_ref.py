@@ -9,7 +9,7 @@ checker for the HIP engine: only ``tests/``, ``__graft_entry__.smoke()`` and the
 Pinning: the reference ships no tests and no golden vectors, and the
 trained checkpoints are gated / absent, so the oracle is pinned against outputs of
 the reference itself, imported in the build container on CPU with seeded random
-weights (``tools/make_goldens.py`` -> ``tests/golden/*.safetensors``).  On those
+weights (``tests/make_goldens.py`` -> ``tests/golden/*.safetensors``).  On those
 fixtures the oracle is bit-identical to the reference (``tests/test_oracle_golden.py``).
 Trained-weight parity: unpinned.
 

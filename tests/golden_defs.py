@@ -1,6 +1,6 @@
 """Shared definitions for the golden fixtures (sizes, sampler option sets, seeded inputs).
 
-Used by tools/make_goldens.py (which runs the reference) and by the tests (which run the oracle
+Used by tests/make_goldens.py (which runs the reference) and by the tests (which run the oracle
 and the HIP engine on the same inputs).  Pure data + torch RNG; no reference code.
 """
 from __future__ import annotations

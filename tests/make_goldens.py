@@ -3,7 +3,7 @@
 
 Run in the build container only (the reference never travels to the GPU box):
 
-    python tools/make_goldens.py
+    python tests/make_goldens.py
 
 What it does: builds the reference's own nn.Modules (model.EchoDiT, autoencoder.DAC) at small
 sizes, loads seeded weights produced by oracle.echo_ref.make_*_weights (the recipe is repo code,

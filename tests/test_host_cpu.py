@@ -50,6 +50,15 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn), encoding="utf-8").read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{fn} mentions the oracle"
+    # tools/ are product-side utilities too; scripts that need the checker live under tests/ (make_goldens.py, bench_encode.py)
+    for fn in os.listdir(os.path.join(ROOT, "tools")):
+        if fn.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "tools", fn), encoding="utf-8").read()
+            assert "from oracle" not in src and "import oracle" not in src, f"tools/{fn} imports the oracle"
+    # bench.py may use it in the cpu_baseline leg only: a single import site, inside cpu_baseline()
+    bsrc = open(os.path.join(ROOT, "bench.py"), encoding="utf-8").read()
+    assert bsrc.count("from oracle") + bsrc.count("import oracle") == 1
+    assert bsrc.index("def cpu_baseline") < bsrc.index("from oracle") < bsrc.index("def host_threads")
 
 
 def test_tokenizer_and_masks_kat(golden):

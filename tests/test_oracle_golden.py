@@ -1,5 +1,5 @@
 """CPU: the oracle (oracle/echo_ref.py) must reproduce, bit for bit, what the reference itself
-produced on the same seeded weights and inputs (tests/golden/*, made by tools/make_goldens.py)."""
+produced on the same seeded weights and inputs (tests/golden/*, made by tests/make_goldens.py)."""
 import hashlib
 
 import pytest
