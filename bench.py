@@ -271,7 +271,7 @@ def main() -> None:
             ms.append(1e3 * (time.perf_counter() - t0s))
         best = sorted(ms[1:])[1]
         single = {"value": round(AUDIO_S / (best * 1e-3), 3), "unit": "audio-s/s", "ms_per_utterance": round(best, 2),
-                  "workload": "C2: one utterance per sampler call (M = 1920 / 640 GEMM rows)"}
+                  "workload": f"{'C5' if args.c5 else 'C2'}: one utterance per sampler call (M = 1920 / 640 GEMM rows), {n_steps} steps"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg belongs to the N=1 line only
         cpu = cpu_baseline(host_threads())
