@@ -94,6 +94,7 @@ struct EngineBase {
   echo_profile prof{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
   std::vector<double> gemm_event_flops;   // > 0: a gemm_pp_kernel launch (plan cfg 5) with that many algorithmic FLOPs
+  std::vector<std::vector<long>> gemm_event_shape;   // ECHO_PROFILE_SHAPES=1: {M, N, K, taps, swiglu, qkv_mode, fp8, cfg, ksplit} per launch
   size_t gemm_events_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> attn_events;
   size_t attn_events_used = 0;
@@ -361,6 +362,8 @@ struct Engine : EngineBase {
       }
       if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
       gemm_event_flops[gemm_events_used] = g.cfg == 5 ? 2.0 * g.M * g.N * g.K * g.taps * g.nbatch : 0.0;
+      if (gemm_event_shape.size() < gemm_events.size()) gemm_event_shape.resize(gemm_events.size());
+      gemm_event_shape[gemm_events_used] = {g.M, g.N, g.K, g.taps, g.swiglu, g.qkv_mode, g.fp8, g.cfg, g.ksplit, g.nbatch};
       auto& e = gemm_events[gemm_events_used++];
       CK(hipEventRecord(e.first, st));
       CK(launch_gemm_nt<T>(g, st));
@@ -1096,6 +1099,22 @@ struct Engine : EngineBase {
       if (hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) == hipSuccess) {
         prof.ms_gemm_sum += ms; ++prof.n_gemm;
         if (i < gemm_event_flops.size() && gemm_event_flops[i] > 0.0) { prof.ms_pp_sum += ms; ++prof.n_pp; prof.flops_pp += gemm_event_flops[i]; }
+      }
+    }
+    if (getenv("ECHO_PROFILE_SHAPES")) {   // debugging aid: time per GEMM shape of the profiled call
+      std::map<std::vector<long>, std::pair<double, int>> by;
+      for (size_t i = 0; i < gemm_events_used && i < gemm_event_shape.size(); ++i) {
+        float ms = 0.f;
+        if (gemm_event_shape[i].empty() || hipEventElapsedTime(&ms, gemm_events[i].first, gemm_events[i].second) != hipSuccess) continue;
+        auto& a = by[gemm_event_shape[i]];
+        a.first += ms; a.second += 1;
+      }
+      for (auto& kv : by) {
+        const auto& k = kv.first;
+        const double us = 1e3 * kv.second.first / kv.second.second;
+        fprintf(stderr, "[echo] shape M=%ld N=%ld K=%ld taps=%ld swiglu=%ld qkv=%ld fp8=%ld cfg=%ld ksplit=%ld nb=%ld: %d launches, %.1f us avg, %.1f ms total, %.0f TF\n",
+                k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], kv.second.second, us, kv.second.first,
+                2.0 * k[0] * k[1] * k[2] * k[3] * k[9] / (us * 1e-6) / 1e12);
       }
     }
   }
