@@ -938,6 +938,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           }
         }
       } else {
+        // q | k | gate sections.  The rope values (cos, sin) and norm weights of a 16-token x 64-column piece are requested
+        // as ONE batch (four 16-byte + four 8-byte loads) in front of its arithmetic: one exposed L2 round trip per piece
+        // instead of one per 16-column fragment (in-situ: the loads issued one at a time cost 91 us of a 543 us launch at
+        // M = 15360).  Larger batches (a whole row, or a row ahead) pushed the kernel over its 256 registers and spilled
+        // the accumulators.
+        const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg + r)
+        const bool do_rope = sec < 2 && (nd0 >> 7) < p.rope_heads;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 yv[8];
@@ -945,6 +952,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           for (int jn = 0; jn < 8; ++jn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
+          float rs = 0.f;
+          const float4* rp = nullptr;
           if (sec < 2) {
             // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
             // lane, the other 96 in lanes fr + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
@@ -955,30 +964,41 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
               for (int r = 0; r < 4; ++r) ss += yv[jn][r] * yv[jn][r];
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            const float rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg + r)
-            const bool do_rope = (nd0 >> 7) < p.rope_heads;
+            rs = rsqrtf(ss / 128.0f + p.qk_eps);
             const int m = m_base + 16 * i + fr;
             const int pos = p.pos0 + m % p.qkv_S;
-#pragma unroll
-            for (int jn = 0; jn < 8; ++jn) {
-              const int d0 = 16 * jn + 4 * fg;
-              float w4[4];
-              Vec4<T>::unpack(*(const Vec4<T>::raw*)((const T*)p.qk_w + (long)sec * D + nd0 + d0), w4);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
-              if (do_rope) {
-                const float4 cs = *(const float4*)((const float2*)p.rope + (long)pos * 64 + (d0 >> 1));   // two (cos, sin) pairs
-                const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
-                yv[jn][0] = __fsub_rn(__fmul_rn(a0, cs.x), __fmul_rn(b0, cs.y));
-                yv[jn][1] = __fadd_rn(__fmul_rn(a0, cs.y), __fmul_rn(b0, cs.x));
-                yv[jn][2] = __fsub_rn(__fmul_rn(a1, cs.z), __fmul_rn(b1, cs.w));
-                yv[jn][3] = __fadd_rn(__fmul_rn(a1, cs.w), __fmul_rn(b1, cs.z));
-              }
-            }
+            rp = (const float4*)((const float2*)p.rope + (long)pos * 64) + fg;     // pairs 8 jn + 2 fg, + 1
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+            if (sec < 2) {
+              float4 cs[4];
+              uint2 w4p[4];
+              const T* wp = (const T*)p.qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
+              if (do_rope) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h + j)];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int jn = 4 * h + j;
+                float w4[4];
+                Vec4<T>::unpack(w4p[j], w4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
+                if (do_rope) {
+                  const float4 c4 = cs[j];                       // two (cos, sin) pairs
+                  const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
+                  yv[jn][0] = __fsub_rn(__fmul_rn(a0, c4.x), __fmul_rn(b0, c4.y));
+                  yv[jn][1] = __fadd_rn(__fmul_rn(a0, c4.y), __fmul_rn(b0, c4.x));
+                  yv[jn][2] = __fsub_rn(__fmul_rn(a1, c4.z), __fmul_rn(b1, c4.w));
+                  yv[jn][3] = __fadd_rn(__fmul_rn(a1, c4.w), __fmul_rn(b1, c4.z));
+                }
+              }
+            }
             const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
             rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
               const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
