@@ -354,6 +354,19 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     dst[5] = __builtin_amdgcn_s_memtime() - k_t0; dst[6] = __builtin_amdgcn_s_memrealtime() - k_r0; dst[7] = pt[7] | (pa << 20) | (pb << 40);   // up to the end of the tile loop
   }
 
+  // the output gate values of this lane's 64 columns are requested now (one batch of 16 x 8 bytes, kh = 0 waves only): issued
+  // one by one inside the store loop each load would wait behind the previous store (a single in-order vmcnt) - 16 L2 round
+  // trips per workgroup instead of one that is hidden by the merge below
+  uint2 gq[4][4];
+  {
+    const bf16_t* gp0 = p.G ? p.G + (long)row * p.g_row_stride + (long)qc * p.g_ld + head * HD + 4 * fh : nullptr;
+    if (gp0 && kh == 0) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[d][g] = *(const uint2*)(gp0 + 32 * d + 8 * g);
+    }
+  }
   // ---- merge the two key halves of each query block: waves kh = 1 park (O, m, l) in LDS, waves kh = 0 combine
   __syncthreads();
   float* mo = (float*)smem + qb * (64 * 66);      // per query block: 64 lanes x (64 O values + m + l), lane-major stride 66
@@ -393,7 +406,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[d][4 * g + i] * inv_l));
       if (gp) {
         float gv[4];
-        Vec4<bf16_t>::unpack(*(const uint2*)(gp + col), gv);
+        Vec4<bf16_t>::unpack(gq[d][g], gv);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_f(gv[i])));
       }
