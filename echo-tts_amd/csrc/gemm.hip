@@ -58,18 +58,46 @@ struct TileCfg {
 };
 
 // ---- fused tail (one rounding to T wherever eager PyTorch materialises a tensor)
+// Split into the loads (per-column vectors and the residual row) and the arithmetic + stores: CDNA4 has ONE in-order vmcnt
+// for loads and stores, so a load issued behind a store waits for that store's round trip too.  The epilogues request the
+// operands of output chunk k + 1 before they store chunk k.
+struct TailCols { float bias[4], cs[4], al[4]; };   // per-column operands of 4 consecutive output columns
+
 template <typename T>
-__device__ __forceinline__ void gemm_tail(const GemmArgs& p, int m, int n0, float (&y)[4], int zo, int zi, T* C, T* C2) {
+__device__ __forceinline__ void gemm_tail_cols(const GemmArgs& p, int n0, int zo, int zi, TailCols& t) {
+  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
+  if (p.bias) {
+    const long bo = zo * p.bias_bo + zi * p.bias_bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.bias[i] = vec_at<T>(p.bias, bo + nv + i);
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.cs[i] = vec_at<T>(p.colscale, nv + i);
+  }
+  if (p.snake_alpha) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.al[i] = vec_at<T>(p.snake_alpha, nv + i);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_tail_res(const GemmArgs& p, int m, int n0, int zo, int zi, float (&r)[4]) {
+  typedef Vec4<T> V;
+  if (p.res) V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_tail_apply(const GemmArgs& p, int m, int n0, float (&y)[4], const TailCols& t, const float (&res)[4], T* C,
+                                                T* C2) {
   typedef Vec4<T> V;
   if (p.acc_scale != 1.0f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
   }
-  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
   if (p.bias) {
-    const long bo = zo * p.bias_bo + zi * p.bias_bi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] += vec_at<T>(p.bias, bo + nv + i);
+    for (int i = 0; i < 4; ++i) y[i] += t.bias[i];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
@@ -86,25 +114,32 @@ __device__ __forceinline__ void gemm_tail(const GemmArgs& p, int m, int n0, floa
   }
   if (p.colscale) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * vec_at<T>(p.colscale, nv + i));
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * t.cs[i]);
   }
   if (p.res) {
-    float r[4];
-    V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
+    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + res[i]);
   }
   if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
   if (p.snake_alpha) {
     float sn4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float al = vec_at<T>(p.snake_alpha, nv + i);
+      const float al = t.al[i];
       const float sn = sinf(al * y[i]);
       sn4[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
     }
     *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
   }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_tail(const GemmArgs& p, int m, int n0, float (&y)[4], int zo, int zi, T* C, T* C2) {
+  TailCols t;
+  float res[4] = {0.f, 0.f, 0.f, 0.f};
+  gemm_tail_cols<T>(p, n0, zo, zi, t);
+  gemm_tail_res<T>(p, m, n0, zo, zi, res);
+  gemm_tail_apply<T>(p, m, n0, y, t, res, C, C2);
 }
 
 template <typename T>
@@ -145,6 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
   constexpr int NPASS = BM / 32;
   // DRAIN: the slab reuses the staging buffers, so every LDS-DMA of the main loop must have landed first
   if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0);
+  TailCols tcols;   // per-column tail operands of this thread's chunk (generic branch), read in the first pass
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     // raw barriers + lgkmcnt only: __syncthreads() would also wait (vmcnt) for the previous pass's global stores
@@ -242,15 +278,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         }
       }
     } else {
+      // every thread keeps ONE 4-column chunk for the whole tile (threads beyond the last full row of chunks idle), so the
+      // per-column operands are read once per tile; rows advance by NT / CPR per step and the residual of step k + 1 is
+      // requested before step k is stored
+      constexpr int RPS = NT / CPR, NTA = RPS * CPR, ITER = (32 + RPS - 1) / RPS;
+      const int chunk = tid % CPR, r0 = tid / CPR;
+      const int n0 = tile_n * BN + chunk * 4;
+      const bool col_ok = tid < NTA && n0 < p.N;
+      if (pass == 0 && col_ok) gemm_tail_cols<T>(p, n0, zo, zi, tcols);
+      float rs[2][4];
+      if (col_ok && r0 < 32 && mrow0 + r0 < p.M) gemm_tail_res<T>(p, mrow0 + r0, n0, zo, zi, rs[0]);
 #pragma unroll
-      for (int idx = tid; idx < 32 * CPR; idx += NT) {
-        const int ml = idx / CPR, chunk = idx % CPR;
-        const int m = mrow0 + ml;
-        const int n0 = tile_n * BN + chunk * 4;
-        if (m >= p.M || n0 >= p.N) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
-        float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-        gemm_tail<T>(p, m, n0, y, zo, zi, C, C2);
+      for (int k = 0; k < ITER; ++k) {
+        const int ml = r0 + k * RPS, m = mrow0 + ml;
+        if (k + 1 < ITER) {
+          const int ml2 = ml + RPS;
+          if (col_ok && ml2 < 32 && mrow0 + ml2 < p.M) gemm_tail_res<T>(p, mrow0 + ml2, n0, zo, zi, rs[(k + 1) & 1]);
+        }
+        if (col_ok && ml < 32 && m < p.M) {
+          const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
+          float y[4] = {a4[0], a4[1], a4[2], a4[3]};
+          gemm_tail_apply<T>(p, m, n0, y, tcols, rs[k & 1], C, C2);
+        }
       }
     }
     EPI_STAMP(t_rw);
