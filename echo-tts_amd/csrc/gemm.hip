@@ -1073,18 +1073,26 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           unpack8_bf16(n0 < p.N ? *(const uint4*)((const T*)p.colscale + n0) : uint4{0, 0, 0, 0}, cs[h]);
         }
       }
+      // the residual chunks of piece pc + 1 are requested before piece pc goes through LDS and is stored: a load issued
+      // behind a store would wait for that store's round trip too (one in-order vmcnt), once per piece
+      uint4 rq[2][2];
+      auto load_res = [&](int pc, uint4 (&r)[2]) __attribute__((always_inline)) {
+        const int i = pc >> 1, h = pc & 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          r[it] = uint4{0, 0, 0, 0};
+          const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
+          if (resp && (full || (m < p.M && n0 < p.N))) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
+        }
+      };
+      load_res(0, rq[0]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          uint4 rr[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
-          if (resp) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-              const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
-              if (full || (m < p.M && n0 < p.N)) rr[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
-            }
-          }
+          const int pc = 2 * i + h;
+          if (pc + 1 < 8) load_res(pc + 1, rq[(pc + 1) & 1]);
+          const uint4 (&rr)[2] = rq[pc & 1];
 #pragma unroll
           for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr * 16 + ((c * 4 + fg) ^ fr)) * 4) = acc[i][4 * h + c];
 #pragma unroll
