@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
         float gv[4];
         Vec4<bf16_t>::unpack(gq[d][g], gv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_f(gv[i])));
+        for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
       }
       *(uint2*)(op + col) = Vec4<bf16_t>::pack(y);
     }

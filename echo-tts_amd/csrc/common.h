@@ -92,7 +92,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// bf16 outputs only: v_exp_f32 + v_rcp_f32 (~2 ulp of fp32, far below the bf16 rounding that follows) instead of the ~25-instruction
+// expf + IEEE division; the fp32 parity engine keeps silu_f
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // bf16 outputs only (see silu_fast)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)

@@ -149,7 +149,7 @@ __device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, co
   for (int i = 0; i < 4; ++i) {
     const float a = Num<T>::rnd(a4[i]);
     const float bb = Num<T>::rnd(b4[i]);
-    o[i] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
+    o[i] = Num<T>::rnd(Num<T>::rnd(Num<T>::is_bf16 ? silu_fast(a) : silu_f(a)) * bb);
   }
   *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + j0) = Vec4<T>::pack(o);
 }
@@ -944,7 +944,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float a = Num<T>::rnd(acc[i][2 * k][r]), bb = Num<T>::rnd(acc[i][2 * k + 1][r]);
-            v4[k][r] = Num<T>::rnd(Num<T>::rnd(silu_f(a)) * bb);
+            v4[k][r] = Num<T>::rnd(Num<T>::rnd(silu_fast(a)) * bb);
           }
         rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
           const int m = m_base + 16 * i + row, j0 = j_base + 8 * c8;
