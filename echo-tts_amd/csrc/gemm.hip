@@ -61,7 +61,7 @@ struct TileCfg {
 // Split into the loads (per-column vectors and the residual row) and the arithmetic + stores: CDNA4 has ONE in-order vmcnt
 // for loads and stores, so a load issued behind a store waits for that store's round trip too.  The epilogues request the
 // operands of output chunk k + 1 before they store chunk k.
-struct TailCols { float bias[4], cs[4], al[4]; };   // per-column operands of 4 consecutive output columns
+struct TailCols { float bias[4], cs[4], al[4], ial[4]; };   // per-column operands of 4 consecutive output columns (ial = 1 / (alpha + 1e-9))
 
 template <typename T>
 __device__ __forceinline__ void gemm_tail_cols(const GemmArgs& p, int n0, int zo, int zi, TailCols& t) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void gemm_tail_cols(const GemmArgs& p, int n0, int zo
   }
   if (p.snake_alpha) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t.al[i] = vec_at<T>(p.snake_alpha, nv + i);
+    for (int i = 0; i < 4; ++i) { t.al[i] = vec_at<T>(p.snake_alpha, nv + i); t.ial[i] = 1.0f / (t.al[i] + 1e-9f); }
   }
 }
 
@@ -127,7 +127,7 @@ __device__ __forceinline__ void gemm_tail_apply(const GemmArgs& p, int m, int n0
     for (int i = 0; i < 4; ++i) {
       const float al = t.al[i];
       const float sn = sinf(al * y[i]);
-      sn4[i] = Num<T>::rnd(y[i] + (1.0f / (al + 1e-9f)) * (sn * sn));
+      sn4[i] = Num<T>::rnd(y[i] + t.ial[i] * (sn * sn));      // the reciprocal is a per-column constant: same value, divided once per tile
     }
     *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
   }
