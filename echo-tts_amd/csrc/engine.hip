@@ -291,7 +291,7 @@ struct Engine : EngineBase {
       }
       if (it == plans.end()) {
       const long t128 = (long)((g.M + 127) / 128) * (g.Npad / 128);
-      if (tune_enabled && (long)g.M * g.N * g.K * g.taps >= (1L << 28)) {
+      if (tune_enabled && (long)g.M * g.N * g.K * g.taps >= (1L << 26)) {
         // time every candidate on the real operands with a scratch output (the tail is irrelevant for the ranking)
         GemmArgs t = g;
         const long out_el = ((long)g.M + 256) * (g.ldc > g.Npad ? g.ldc : g.Npad);
