@@ -21,7 +21,7 @@ single-request configuration (C2 proper); its throughput is measured in the same
 as a serving process does with independent requests (handler.py:747-759): the second call's kernels fill the CUs that
 the last, partial round of 256x256 tiles of the first leaves idle (+6 % measured; `--concurrency 1` for one call).
 Measured sweep (audio-s/s, batch x concurrency, round-1 v7 binaries): 1x1 97, 4x1 134, 4x2 148, 8x2 157, 12x2 160, 16x2 161;
-v10 binaries: 8x2 168.
+v11 binaries: 8x2 164-172.
 
 Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
 utterances); the only collective in the job is the start-up broadcast of the frozen weights from
