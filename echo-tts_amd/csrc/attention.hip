@@ -323,9 +323,11 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     k_advance();                      // ks -> tile 2, vs -> tile 1, cur = tile 0
     v_advance();
     if (PROF) pt[7] = __builtin_amdgcn_s_memtime() - k_t0;   // prologue
-    // tile t is in `sa`; Sᵀ of tile t+1 is produced into `sb` and moved over at the end of the step
-#pragma unroll 1
-    for (int t = 0; t < total_tiles; ++t) {
+    // One step: tile t is in `scur`; Sᵀ of tile t+1 is produced into `snext`.  The loop is unrolled by two with the score
+    // tiles exchanging roles and the ring slots as compile-time constants (PAR = t & 1): no 16-register copy per tile and
+    // the LDS read / DMA addresses are a per-lane offset + an immediate.
+    auto step = [&](auto par, f32x16& scur, f32x16& snext) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par)::value;
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
       if (PROF) t0 = stamp();
       // Every wave's DMA pieces of K(t+1) / V(t) must have landed before anyone reads them.  hipcc does NOT put the
@@ -337,15 +339,21 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       if (PROF) t1 = stamp();
       // next DMA targets: K(t+2) -> K slot t&1, V(t+1) -> V slot (t+1)&1.  Past the end the streams stay on the last
       // tile: the redundant pieces land in slots nobody reads again (and are drained before the merge).
-      char* kdst = kring + (t & 1) * K_TILE_BYTES + wid * 2048;
-      char* vdst = vring + ((t + 1) & 1) * V_TILE_BYTES + wid * 2048;
-      if (tile_needs_mask()) apply_mask(sa);
+      char* kdst = kring + PAR * K_TILE_BYTES + wid * 2048;
+      char* vdst = vring + (PAR ^ 1) * V_TILE_BYTES + wid * 2048;
+      if (tile_needs_mask()) apply_mask(scur);
       if (PROF) t2 = stamp();
-      compute(sa, sb, kring + ((t + 1) & 1) * K_TILE_BYTES, vring + (t & 1) * V_TILE_BYTES, kdst, vdst);
+      compute(scur, snext, kring + (PAR ^ 1) * K_TILE_BYTES, vring + PAR * V_TILE_BYTES, kdst, vdst);
       if (PROF) { const unsigned long long t3 = stamp(); pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += 1; }
-      sa = sb;
       k_advance(); v_advance(); c_advance();
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < total_tiles; t += 2) {
+      step(std::integral_constant<int, 0>{}, sa, sb);
+      step(std::integral_constant<int, 1>{}, sb, sa);
     }
+    if (t < total_tiles) step(std::integral_constant<int, 0>{}, sa, sb);   // odd tile count: the last tile has even parity
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the rings are reused / the workgroup ends
   if (PROF && lane == 0) {
