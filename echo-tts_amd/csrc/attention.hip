@@ -262,14 +262,14 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       m_i = m_new;
     }
     const float mc = m_i * c;
-    float rs = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) snext[r] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       snext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], snext, 0, 0, 0);
-      { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kk], c, -mc)); scur[kk] = pv; rs += pv; }
+      // no consumer right behind the exponential (an exp -> add chain stalls the in-order wave); the row sum is formed at the end
+      scur[kk] = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kk], c, -mc));
       if (kk == 1) glds16(ks.ptr + k_off[0], kdst);            // K(t+2)
       if (kk == 3) glds16(ks.ptr + k_off[1], kdst + 1024);
       if (kk == 5) glds16(vs.ptr + v_off[0], vdst);            // V(t+1)
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int r = 8 + 2 * d + e;
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[r], c, -mc)); scur[r] = pv; rs += pv;
+          scur[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[r], c, -mc));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -294,6 +294,11 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[d], pf, o[d], 0, 0, 0);
     }
+    // row sum in the shadow of the last MFMAs: four independent chains, then a tree
+    float r0 = scur[0] + scur[4], r1 = scur[1] + scur[5], r2 = scur[2] + scur[6], r3 = scur[3] + scur[7];
+    r0 += scur[8]; r1 += scur[9]; r2 += scur[10]; r3 += scur[11];
+    r0 += scur[12]; r1 += scur[13]; r2 += scur[14]; r3 += scur[15];
+    float rs = (r0 + r1) + (r2 + r3);
     rs += __shfl_xor(rs, 32, 64);
     l_i += rs;
   };
