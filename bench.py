@@ -63,7 +63,7 @@ def dit_gemm_flops(batch: int = 1, steps: int = STEPS) -> float:
     return float(batch * rows * per_row + mod)
 
 
-def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, fp8: bool = False):
+def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, fp8: bool = False, keep_state: bool = False):
     import echo_tts_amd as E
     from echo_tts_amd import parallel as P
     from echo_tts_amd.weights import dac_param_shapes, dit_param_shapes, random_dac_state, random_dit_state
@@ -73,11 +73,11 @@ def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, f
     sd = P.broadcast_state(dit_param_shapes(cfg, with_blockwise=False), sd, device, torch.bfloat16)
     # one engine context (packed weights + KV caches + workspaces) per concurrent request slot
     models = [E.EchoDiT(cfg, sd, dtype=torch.bfloat16, device=device, fp8=fp8) for _ in range(concurrency)]
-    del sd
     dsd = random_dac_state(dcfg, device, seed=0) if rank == 0 else None
     dsd = P.broadcast_state(dac_param_shapes(dcfg), dsd, device, torch.float32)
     dacs = [E.DAC(dcfg, dsd, device=device) for _ in range(concurrency)]
-    del dsd
+    state = {"dit": sd, "dac": dsd} if keep_state else None      # reference-named checkpoints for the baseline legs (rank 0)
+    del sd, dsd
     torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(1234)
     q, _ = torch.linalg.qr(torch.randn(dcfg.latent_dim, cfg.latent_size, generator=g))
@@ -89,52 +89,84 @@ def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, f
     spk = torch.randn((1, TS, cfg.latent_size), generator=g).to(device)
     smask = torch.ones((1, TS), dtype=torch.bool)
     if batch > 1:
-        # the reference's own batch axis (inference.py:448-449): `batch` utterances through one sampler call, each with its
-        # own noise; every row carries its own text / speaker KV like any (B, ...) call of the reference
-        ids, tmask, spk, smask = ids.repeat(batch, 1), tmask.repeat(batch, 1), spk.repeat(batch, 1, 1), smask.repeat(batch, 1)
-    return E, models, dacs, pca, ids.to(device), tmask, spk, smask
+        # the reference's own batch axis (inference.py:448-449): `batch` utterances through one sampler call, each with its own
+        # noise and its own text KV; the ONE reference voice (C3: "same speaker"; the chunks of a handler request,
+        # handler.py:747-759) is encoded once per call - inside the timed region - and shared by all rows (stride-0 KV)
+        ids, tmask = ids.repeat(batch, 1), tmask.repeat(batch, 1)
+    return E, models, dacs, pca, ids.to(device), tmask, spk, smask, state
 
 
-def cpu_baseline(threads: int):
-    """The CPU oracle (plain PyTorch restatement of the reference, bf16 DiT + fp32 DAC like the GPU run) on the host
-    cores, on a bounded sample of the same workload, extrapolated linearly in layers / steps / frames."""
+def cpu_baseline(threads: int, state, pca, ids, tmask, spk, smask):
+    """The CPU oracle (plain PyTorch restatement of the reference: bf16 EchoDiT + fp32 DAC like the GPU run) on the host cores,
+    on the REAL 24-layer model with the bench's own weights and inputs: text + speaker KV encode in full, one 3-row
+    CFG forward and one 1-row forward at S = 640 (the two step kinds of the schedule, each measured once after a warm-up of the
+    1-row kind), DAC decode of 64 of the 640 frames.  Whole-utterance time = encoders + 20 x t3 + 20 x t1 + decode x 10."""
     from oracle import echo_ref as R
     torch.set_num_threads(threads)
-    nl = 2
-    cfg = R.DiTConfig(num_layers=nl, text_num_layers=1, speaker_num_layers=1)
-    w = {k: v.bfloat16() for k, v in R.make_dit_weights(cfg, seed=0, with_blockwise=False).items()}
+    cfg, dcfg = R.DiTConfig(), R.DacConfig()
+    w = {k: v.to("cpu") for k, v in state["dit"].items()}
+    dw = {k: v.to("cpu") for k, v in state["dac"].items()}
+    ids1, tm1, spk1, sm1 = ids[:1].cpu(), tmask[:1].cpu(), spk[:1].cpu().bfloat16(), smask[:1].cpu()
     g = torch.Generator().manual_seed(0)
-    x = torch.randn((1, S, 80), generator=g).bfloat16()
-    tm = torch.zeros((1, TVALID), dtype=torch.bool)
-    tm[:] = True
-    sm = torch.ones((1, TS // 4), dtype=torch.bool)
-    kvt = [(torch.randn((1, TVALID, 16, 128), generator=g).bfloat16(), torch.randn((1, TVALID, 16, 128), generator=g).bfloat16())
-           for _ in range(nl)]
-    kvs = [(torch.randn((1, TS // 4, 16, 128), generator=g).bfloat16(), torch.randn((1, TS // 4, 16, 128), generator=g).bfloat16())
-           for _ in range(nl)]
-    smf = torch.ones((1, TS), dtype=torch.bool)
+    x = torch.randn((1, S, 80), generator=g)
+    pc = R.PCA(pca.pca_components.cpu(), pca.pca_mean.cpu(), float(pca.latent_scale))
     with torch.inference_mode():
+        t0 = time.perf_counter()
+        kvt = R.kv_cache_text(w, cfg, ids1, tm1)
+        kvs = R.kv_cache_speaker(w, cfg, spk1)
+        tenc = time.perf_counter() - t0
+        kvt3, kvs3 = R._cat3(kvt), R._cat3(kvs)
+        tm3 = torch.cat([tm1, torch.zeros_like(tm1), tm1], 0)
+        sm3 = torch.cat([sm1, sm1, torch.zeros_like(sm1)], 0)
+
         def fwd(rows):
-            xx = torch.cat([x] * rows, 0)
-            tt = torch.full((rows,), 0.7).bfloat16()
-            k3 = [(torch.cat([k] * rows, 0), torch.cat([v] * rows, 0)) for k, v in kvt]
-            s3 = [(torch.cat([k] * rows, 0), torch.cat([v] * rows, 0)) for k, v in kvs]
+            xx = torch.cat([x] * rows, 0).bfloat16()
+            tt = (torch.ones((rows,)) * 0.7).bfloat16()
             t0 = time.perf_counter()
-            R.dit_forward(w, cfg, xx, tt, torch.cat([tm] * rows, 0), torch.cat([smf] * rows, 0), k3, s3)
+            if rows == 3:
+                R.dit_forward(w, cfg, xx, tt, tm3, sm3, kvt3, kvs3)
+            else:
+                R.dit_forward(w, cfg, xx, tt, tm1, sm1, kvt, kvs)
             return time.perf_counter() - t0
         fwd(1)
         t3, t1 = fwd(3), fwd(1)
-        dcfg = R.DacConfig()
-        dw = R.make_dac_weights(dcfg, 0)
-        z = torch.randn((1, dcfg.latent_dim, 16), generator=g)
+        nf = 64
+        lat = torch.randn((1, nf, 80), generator=g)
         t0 = time.perf_counter()
-        R.dac_decode_zq(dw, dcfg, z)
+        R.ae_decode(dw, dcfg, pc, lat)
         tdac = time.perf_counter() - t0
-    est = (20 * t3 + 20 * t1) * (24 / nl) + tdac * (S / 16)
+    est = tenc + 20 * t3 + 20 * t1 + tdac * (S / nf)
     return {"value": AUDIO_S / est, "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/echo_ref.py, torch CPU eager bf16 DiT + fp32 DAC: one 3-row and one 1-row EchoDiT forward at S=640 with "
-                      f"{nl} of 24 layers ({t3:.2f}s, {t1:.2f}s) scaled x12 layers x20 steps each, DAC decode of 16 of 640 frames "
-                      f"({tdac:.2f}s) scaled x40; KV encoders excluded; estimated {est:.0f}s per utterance"}
+            "sample": f"oracle/echo_ref.py, torch {torch.__version__} CPU eager, bf16 EchoDiT + fp32 DAC, the bench's 24-layer weights and inputs: "
+                      f"text + speaker KV encode in full ({tenc:.2f}s), one 3-row CFG forward ({t3:.2f}s) and one 1-row forward ({t1:.2f}s) at S=640 "
+                      f"x 20 steps each, DAC decode of {nf} of 640 frames ({tdac:.2f}s) x 10; estimated {est:.0f}s per utterance"}
+
+
+def eager_gpu_baseline(state, pca, ids, tmask, spk, smask, sampler_kw, device):
+    """SURVEY.md 8d / BASELINE.md 4: the reference's own execution model on this GPU - the oracle's torch ops run eagerly
+    through PyTorch-ROCm (bf16 EchoDiT sampler, fp32 DAC decode), one utterance end to end (C2 proper), same weights and inputs.
+    The oracle is only ever the baseline here, never the product path."""
+    from oracle import echo_ref as R
+    cfg, dcfg = R.DiTConfig(), R.DacConfig()
+    w, dw = state["dit"], state["dac"]
+    pc = R.PCA(pca.pca_components.to(device), pca.pca_mean.to(device), float(pca.latent_scale))
+    a = (spk[:1].to(device), smask[:1].to(device), ids[:1].to(device), tmask[:1].to(device))
+    times = {}
+    with torch.inference_mode():
+        for it in range(2):                    # first pass warms code objects / MIOpen solvers
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat = R.sample_euler(w, cfg, torch.bfloat16, *a, rng_seed=it, **sampler_kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            wav = R.ae_decode(dw, dcfg, pc, lat)
+            torch.cuda.synchronize()
+            times = {"sampler_ms": 1e3 * (t1 - t0), "dac_ms": 1e3 * (time.perf_counter() - t1)}
+    tot = (times["sampler_ms"] + times["dac_ms"]) * 1e-3
+    return {"value": round(AUDIO_S / tot, 3), "unit": "audio-s/s", "kind": "port (oracle ops, PyTorch-ROCm eager on the same MI355X)",
+            "ms_per_utterance": round(1e3 * tot, 1), "sampler_ms": round(times["sampler_ms"], 1), "dac_decode_ms": round(times["dac_ms"], 1),
+            "finite": bool(torch.isfinite(wav).all()),
+            "workload": f"one utterance per call, {sampler_kw['num_steps']} steps, bf16 EchoDiT + fp32 DAC, second of two runs"}
 
 
 def host_threads() -> int:
@@ -156,6 +188,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=2,
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
@@ -182,7 +215,8 @@ def main() -> None:
     nb = max(1, args.batch)
     n_steps = 100 if args.c5 else STEPS
     sampler_kw = dict(SAMPLER, num_steps=n_steps)
-    E, models, dacs, pca, ids, tmask, spk, smask = build(device, rank, world, conc, nb, fp8=args.c5)
+    want_base = rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_eager_baseline)
+    E, models, dacs, pca, ids, tmask, spk, smask, state = build(device, rank, world, conc, nb, fp8=args.c5, keep_state=want_base)
     model, dac = models[0], dacs[0]
     streams = [torch.cuda.Stream(device=device) for _ in range(conc)] if conc > 1 else [torch.cuda.current_stream(device)]
 
@@ -261,7 +295,7 @@ def main() -> None:
     single = None
     if rank == 0 and nb * conc > 1 and not args.no_roofline:
         # the same engine on one utterance at a time (BASELINE config C2 proper), 1 warm-up + 3 timed
-        i1, t1, s1, m1 = ids[:1], tmask[:1], spk[:1], smask[:1]
+        i1, t1, s1, m1 = ids[:1], tmask[:1], spk, smask
         ms = []
         for i in range(4):
             torch.cuda.synchronize()
@@ -273,9 +307,29 @@ def main() -> None:
         best = sorted(ms[1:])[1]
         single = {"value": round(AUDIO_S / (best * 1e-3), 3), "unit": "audio-s/s", "ms_per_utterance": round(best, 2),
                   "workload": f"{'C5' if args.c5 else 'C2'}: one utterance per sampler call (M = 1920 / 640 GEMM rows), {n_steps} steps"}
-    cpu = None
+    c3 = None
+    if rank == 0 and nb >= 4 and not args.no_roofline:
+        # BASELINE config C3's per-GPU share: 4 utterances per sampler call, one call at a time (32 utterances / 8 GPUs)
+        ms = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            lat4 = E.sample_euler_cfg_independent_guidances(model, spk, smask, ids[:4], tmask[:4], rng_seed=70 + i, **sampler_kw)
+            E.ae_decode(dac, pca, lat4)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0s))
+        best = sorted(ms)[1]
+        c3 = {"value": round(4 * AUDIO_S / (best * 1e-3), 3), "unit": "audio-s/s", "ms_per_call": round(best, 2),
+              "workload": "C3 per-GPU share: 4 utterances per sampler call, 1 call in flight (M = 7680 / 2560 GEMM rows)"}
+    cpu = eager = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg belongs to the N=1 line only
-        cpu = cpu_baseline(host_threads())
+        cpu = cpu_baseline(host_threads(), state, pca, ids, tmask, spk, smask)
+    if rank == 0 and world == 1 and not args.no_eager_baseline:
+        try:
+            eager = eager_gpu_baseline(state, pca, ids, tmask, spk, smask, sampler_kw, device)
+        except Exception as ex:      # a baseline must never take the bench line down
+            eager = {"error": f"{type(ex).__name__}: {ex}"}
+    state = None
 
     if rank == 0:
         total_audio = AUDIO_S * args.steps * world * conc * nb
@@ -288,10 +342,10 @@ def main() -> None:
             "per_gpu": round(total_audio / dt / world, 3),
             "config": {"workload": f"{'C5' if args.c5 else 'C2'}: {conc * nb} utterance(s)/step/GPU ({nb} per sampler call, {conc} HIP stream(s)), seq_len=640, "
                                    f"{n_steps} Euler steps ({n_steps // 2} CFG x3 rows + {n_steps - n_steps // 2} x1 row), "
-                                   "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, speaker latent (1,2560,80), "
+                                   "cfg_text=3.0 cfg_spk=8.0, text 436 tokens padded to 768, one speaker latent (1,2560,80) encoded per call and shared by its rows, "
                                    + ("EchoDiT fp8-e4m3 block GEMMs" if args.c5 else "EchoDiT bf16") + " + Fish S1-DAC decode fp32, random weights",
                        "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
-            "roofline": roofline, "cpu_baseline": cpu, "single_request": single, "phases": phases,
+            "roofline": roofline, "cpu_baseline": cpu, "eager_gpu_baseline": eager, "single_request": single, "c3_share": c3, "phases": phases,
         }
         print(json.dumps(out))
     if world > 1:

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -69,7 +69,9 @@ class EchoGemmDesc(C.Structure):
                 ("snake_alpha", vp),
                 ("store_main", C.c_int), ("swiglu", C.c_int),
                 ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int),
-                ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp)]
+                ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp),
+                ("qkv_mode", C.c_int), ("qkv_D", C.c_int), ("qkv_S", C.c_int), ("rope_heads", C.c_int), ("pos0", C.c_int), ("qk_eps", C.c_float),
+                ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64)]
 
 
 class EchoAttnSeg(C.Structure):
@@ -126,6 +128,17 @@ SIGNATURES = {
                                         C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "echo_op_transpose_heads": (C.c_int, [C.c_int, vp, c_i64, vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_debug_get_kv": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "echo_voice_capture": (C.c_int, [vp, C.POINTER(vp), vp]),
+    "echo_voice_bind": (C.c_int, [vp, vp, vp]),
+    "echo_voice_bytes": (c_i64, [vp]),
+    "echo_voice_destroy": (None, [vp]),
+    "echo_dac_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
+    "echo_workspace_bytes": (c_i64, [vp]),
+    "echo_reserve_workspace": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "echo_op_find_flattening_point": (C.c_int, [vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
+    "echo_op_trailing_quiet": (C.c_int, [C.POINTER(vp), C.POINTER(c_i64), C.c_int, C.c_int, C.c_float, vp, vp]),
+    "echo_op_assemble_chunks": (C.c_int, [C.POINTER(vp), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_int32),
+                                          C.c_int, vp, c_i64, vp]),
     "echo_set_profiling": (C.c_int, [vp, C.c_int]),
     "echo_get_profile": (C.c_int, [vp, C.POINTER(EchoProfile)]),
 }

@@ -366,6 +366,35 @@ class DAC:
         return out
 
     @torch.no_grad()
+    def decode_latent_tail(self, latent: torch.Tensor, first_frame: int) -> torch.Tensor:
+        """Streaming building block: `latent` (T, latent_size) are all frames so far; returns the (T - first_frame) * hop samples
+        of frames first_frame.. (the post_module transformer sees every frame, the convolutional stack only the tail)."""
+        lat = latent.to(self._device, torch.float32).contiguous()
+        T = lat.shape[0]
+        out = torch.empty(((T - first_frame) * self.config.hop,), dtype=torch.float32, device=self._device)
+        L.check(self._lib.echo_dac_decode_tail(self._ctx, lat.data_ptr(), T, int(first_frame), self._latent_scale, out.data_ptr(),
+                                               self._stream()), self._ctx)
+        return out
+
+    def conv_context_frames(self) -> int:
+        """Latent frames of left context after which the causal convolutional stack (quantizer.upsample + Decoder,
+        autoencoder.py:427-435, 971-998) no longer sees the start of its input: dwconv k7 per upsample stage, conv k7, per block
+        the ConvTranspose (k = 2 stride: one input step) and three ResidualUnits (k7, dilations 1, 3, 9), final conv k7.  Every
+        term is (kernel span in samples) / (samples per latent frame at that layer); rounded up, plus two frames of margin."""
+        c = self.config
+        rate, need = 1.0, 0.0
+        for f in c.upsample_factors:
+            rate *= f
+            need += 6.0 / rate
+        need += 6.0 / rate
+        for r in c.decoder_rates:
+            need += 1.0 / rate
+            rate *= r
+            need += 6.0 * (1 + 3 + 9) / rate
+        need += 6.0 / rate
+        return int(need + 0.999999) + 2
+
+    @torch.no_grad()
     def decode_zq(self, z_q: torch.Tensor) -> torch.Tensor:
         """autoencoder.py:1128-1132: (B, latent_dim, T) -> (B, 1, T*hop)."""
         z = z_q.to(self._device, torch.float32).transpose(1, 2).contiguous()    # channels-last
@@ -376,3 +405,35 @@ class DAC:
         return out
 
 
+
+
+class DACStream:
+    """Causal chunked decode of ONE utterance: feed the latents of each generated block as they arrive and
+    receive exactly the samples of those frames, equal to a whole-utterance `ae_decode` (tests/test_gpu_engine.py: <= 1e-6).
+    The reference decodes whole utterances only (inference.py:226-229, gradio_app.py:43) although every convolution of the
+    decoder is causal (autoencoder.py:264-331); block k is therefore audible while block k + 1 is still being sampled.
+
+    Each `push` re-runs the cheap window-limited transformer (3 % of the decode FLOPs) over the frames so far and the
+    convolutional stack over the new frames plus `context` frames of left context that are decoded again and dropped."""
+
+    def __init__(self, fish_ae: DAC, pca_state, context: Optional[int] = None):
+        self.ae = fish_ae
+        fish_ae.set_pca(pca_state)
+        self.context = fish_ae.conv_context_frames() if context is None else int(context)
+        self.latents: Optional[torch.Tensor] = None
+        self.emitted = 0
+
+    @torch.no_grad()
+    def push(self, block: torch.Tensor) -> torch.Tensor:
+        """block: (n, latent_size) or (1, n, latent_size) new latents -> (1, 1, n * hop) samples of exactly those frames."""
+        if block.dim() == 3:
+            if block.shape[0] != 1:
+                raise ValueError("DACStream decodes one utterance; use one stream per batch item")
+            block = block[0]
+        block = block.to(self.ae.device, torch.float32)
+        self.latents = block if self.latents is None else torch.cat([self.latents, block], dim=0)
+        f0 = max(0, self.emitted - self.context)
+        wav = self.ae.decode_latent_tail(self.latents, f0)
+        wav = wav[(self.emitted - f0) * self.ae.config.hop:]
+        self.emitted = self.latents.shape[0]
+        return wav.view(1, 1, -1)

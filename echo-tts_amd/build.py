@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libechohip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "dac.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "dac.hip", "postproc.hip", "engine.hip"]
 
 
 def _hipcc() -> str:

@@ -204,7 +204,8 @@ struct EulerArgs {
   float s_text, s_spk;
   int rescale; float r_inv1mt, r_ratio, r_1mt;
   float dt;            // t_next - t
-  float init_scale;    // != 0: x = x * init_scale first and no model step (used for truncation / initial cast)
+  int init;            // 1: x = x * init_scale and no model step (truncation_factor, inference.py:478-479; 0.0 is a legal factor) + first model input
+  float init_scale;
 };
 template <typename T> hipError_t launch_euler(const EulerArgs& e, hipStream_t st);
 
@@ -213,6 +214,17 @@ hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch,
                               const float* bias, long bias_batch_stride, int heads_per_bias_row,
                               int causal, int window, hipStream_t st);
 hipError_t launch_mask_to_bias(const uint8_t* mask, float* bias, long n, hipStream_t st);
+
+// ---------------------------------------------------------------- post-processing (postproc.hip)
+#define ECHO_MAX_CHUNKS 64
+// out[b] = first frame of lat[b] (T, W) whose zero-extended window is flat (inference.py:288-296), T if none
+hipError_t launch_flatten_point(const float* lat, long item_stride, int B, int T, int W, int window, float target, float std_thr, int* out,
+                                hipStream_t st);
+// out[c] = trailing samples with |x| < thr among the last min(len, max_window) samples of chunk c (handler.py:199-211); host tables
+hipError_t launch_trailing_quiet(const float* const* chunks, const long* lens, int n, int max_window, float thr, int* out, hipStream_t st);
+// trimmed / zero-padded chunks cross-faded into one waveform (handler.py:126-170, 213-232); host tables
+hipError_t launch_assemble_chunks(const float* const* src, const long* start, const long* len, const long* valid, const int* ov, int n,
+                                  float* out, long total, hipStream_t st);
 
 // ---------------------------------------------------------------- DAC helpers (dac.hip)
 // All take channels-last fp32 activations x[t][c]; S = time steps per batch item (causal padding restarts there).

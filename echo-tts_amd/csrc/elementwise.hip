@@ -235,7 +235,7 @@ __global__ void euler_kernel(const EulerArgs e) {
   const long tok = i / e.L;
   const int l = (int)(i - tok * e.L);
   float x = e.x[i];
-  if (e.init_scale != 0.0f) {
+  if (e.init) {
     if (e.init_scale != 1.0f) x = __fmul_rn(x, e.init_scale);
   } else {
     const T* v = (const T*)e.v;

@@ -4,6 +4,8 @@
 #include "common.h"
 #include "../../include/echo_hip.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +24,45 @@ std::map<int, std::map<std::vector<long>, Plan>> g_plans;   // device -> (shape 
 std::mutex g_plans_mu;                                       // contexts may be driven from different host threads (ctypes drops the GIL)
 
 inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+
+// GEMM plans persist in a text file (one "M N K taps swiglu nbatch esize qkv split3 : cfg ksplit" line per shape) so that every
+// process, rank and box runs a shape with the same tile configuration and split-K factor: the summation order and the bf16
+// rounding points - and with them the output bits for a given seed - no longer depend on the noisy timings of a first-use
+// tuning pass.  ECHO_GEMM_PLANS names the file (default: gemm_plans.txt next to libechohip.so); shapes it does not list are
+// tuned once and, when ECHO_GEMM_PLANS_SAVE names a file, appended there (how the shipped table was produced).
+std::string plan_file_path() {
+  if (const char* e = getenv("ECHO_GEMM_PLANS")) return e;
+  Dl_info info;
+  if (dladdr((const void*)&plan_file_path, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t k = p.find_last_of('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/gemm_plans.txt";
+  }
+  return "gemm_plans.txt";
+}
+void load_plan_file(std::map<std::vector<long>, Plan>& plans) {
+  FILE* f = fopen(plan_file_path().c_str(), "r");
+  if (!f) return;
+  char line[512];
+  while (fgets(line, sizeof(line), f)) {
+    long k[9]; int cfg = 0, ks = 1;
+    if (line[0] == '#') continue;
+    if (sscanf(line, "%ld %ld %ld %ld %ld %ld %ld %ld %ld : %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &cfg, &ks) != 11) continue;
+    if (cfg < 0 || cfg >= gemm_num_cfgs() || ks < 1 || ks > 64) continue;
+    Plan p; p.cfg = cfg; p.ksplit = ks;
+    plans.emplace(std::vector<long>(k, k + 9), p);
+  }
+  fclose(f);
+}
+void append_plan_file(const std::vector<long>& key, const Plan& p, float us) {
+  const char* path = getenv("ECHO_GEMM_PLANS_SAVE");
+  if (!path) return;
+  FILE* f = fopen(path, "a");
+  if (!f) return;
+  for (long v : key) fprintf(f, "%ld ", v);
+  fprintf(f, ": %d %d   # %.1f us\n", p.cfg, p.ksplit, us);
+  fclose(f);
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -84,6 +125,18 @@ __global__ void gate_mul_kernel(T* __restrict__ o, long ldo, const T* __restrict
   o[r * ldo + c] = Num<T>::st(ov * sg);
 }
 
+// A reference voice as the sampler needs it: the speaker encoder's output projected to the K / V (and Vᵀ) of every EchoDiT
+// layer (model.py:615-621), captured from one context and bound to any context of the same model on the same device.
+struct VoiceSnap {
+  DevBuf kv, vt, bias;
+  int device = 0, precision = 0, model_size = 0, num_layers = 0;
+  int B = 0, T = 0, pad = 0, vld = 0;
+  std::vector<int> nk;
+  bool has_bias = false; long bias_ld = 0;
+  size_t kv_bytes = 0, vt_bytes = 0, bias_bytes = 0;
+  ~VoiceSnap() { kv.release(); vt.release(); bias.release(); }
+};
+
 struct EngineBase {
   echo_config cfg{};
   int device = 0;
@@ -129,6 +182,11 @@ struct EngineBase {
   virtual int dac_encode(const float* audio, long n, float* lat, int32_t* codes, float* zq, hipStream_t st) = 0;
   virtual int set_pca_encode(const float* w, const float* bias, float scale, int on_device, hipStream_t st) = 0;
   virtual int debug_get_kv(int which, int layer, float* k, float* v, int* B, int* T) = 0;
+  virtual int voice_capture(struct VoiceSnap** out, hipStream_t st) = 0;
+  virtual int voice_bind(const struct VoiceSnap* v, hipStream_t st) = 0;
+  virtual int dac_decode_tail(const float* lat, int T, int f0, float scale, float* wav, hipStream_t st) = 0;
+  virtual size_t workspace_bytes() = 0;
+  virtual int reserve_workspace(int B, int S, int Tt, int Ts, int T_dac) = 0;
 };
 
 #define CK(x)                                            \
@@ -188,7 +246,8 @@ struct Engine : EngineBase {
             &b_dacA, &b_dacB, &b_dacC, &b_dq, &b_dscore, &b_dvt, &b_dmisc};
   }
   // text / speaker / latent cache geometry
-  int kvB = 0;
+  int kvB = 0;          // batch size of the text cache (= utterances per sampler call)
+  int spkB = 0;         // batch size of the speaker cache: kvB (one voice per utterance) or a divisor of it (1 = one voice shared by all rows)
   int text_T = 0, text_pad = 0, text_vld = 0; std::vector<int> text_nk; bool text_has_bias = false; long text_bias_ld = 0;
   int spk_T = 0, spk_pad = 0, spk_vld = 0; std::vector<int> spk_nk; bool spk_has_bias = false; long spk_bias_ld = 0;
   int lat_T = 0, lat_pad_rows = 0, lat_vld = 0, latB = 0;
@@ -233,7 +292,12 @@ struct Engine : EngineBase {
   static std::map<std::vector<long>, Plan>& plans_of_device() {
     std::lock_guard<std::mutex> lk(g_plans_mu);
     int d = 0; (void)hipGetDevice(&d);
-    return g_plans[d];
+    auto it = g_plans.find(d);
+    if (it == g_plans.end()) {
+      it = g_plans.emplace(d, std::map<std::vector<long>, Plan>()).first;
+      if (!getenv("ECHO_GEMM_FORCE")) load_plan_file(it->second);
+    }
+    return it->second;
   }
   int device_key() { int d = 0; (void)hipGetDevice(&d); return d; }
   DevBuf b_gemm_ws, b_tune_c, b_flush;
@@ -291,15 +355,28 @@ struct Engine : EngineBase {
       }
       if (it == plans.end()) {
       const long t128 = (long)((g.M + 127) / 128) * (g.Npad / 128);
-      if (tune_enabled && (long)g.M * g.N * g.K * g.taps >= (1L << 26)) {
+      if (!tune_enabled) {
+        // ECHO_GEMM_TUNE=0: fixed rules instead of timings (reproducible without a plan file): the ping-pong kernel for
+        // the big bf16 linears, 256-row tiles for long-M fp32 convolutions, 128x128 otherwise
+        const bool big = (long)g.M * g.Npad >= 256L * 256 * 64;
+        if (sizeof(U) == 2 && big && g.nbatch == 1 && g.taps == 1 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (!g.swiglu || (g.N & 15) == 0) &&
+            !g.snake_alpha && !g.C2 && g.act != 2 && g.store_main && (!g.qkv_mode || g.qkv_D % 256 == 0) && (!g.res || (g.ldres & 7) == 0) &&
+            (g.vec_mod & 7) == 0) best.cfg = 5;
+        else if (big && !g.qkv_mode) best.cfg = g.N % 192 == 0 && g.N % 256 != 0 ? 8 : g.N % 96 == 0 && g.N % 128 != 0 ? 9 : 2;
+      } else
+      if ((long)g.M * g.N * g.K * g.taps >= (1L << 26)) {
         // time every candidate on the real operands with a scratch output (the tail is irrelevant for the ranking)
         GemmArgs t = g;
         const long out_el = ((long)g.M + 256) * (g.ldc > g.Npad ? g.ldc : g.Npad);
         CK(b_tune_c.reserve((size_t)out_el * sizeof(U) * (g.nbatch > 1 ? 1 : 1)));
         t.C = b_tune_c.p; t.C2 = nullptr; t.res = nullptr; t.snake_alpha = nullptr; t.store_main = 1; t.colscale = nullptr; t.bias = nullptr; t.qkv_mode = 0;
         if (g.nbatch > 1) { t.nbatch = 1; t.nbi = 1; }
-        hipEvent_t e0, e1;
-        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        struct EvPair {     // destroyed on every exit path (the CK() early returns below run while g_plans_mu is held)
+          hipEvent_t a = nullptr, b = nullptr;
+          ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+        } evp;
+        CK(hipEventCreate(&evp.a)); CK(hipEventCreate(&evp.b));
+        const hipEvent_t e0 = evp.a, e1 = evp.b;
         CK(b_flush.reserve((size_t)512 << 20));
         float best_ms = 1e30f;
         for (int cfg = 0; cfg < gemm_num_cfgs(); ++cfg) {
@@ -332,7 +409,7 @@ struct Engine : EngineBase {
             if (ms < best_ms) { best_ms = ms; best.cfg = cfg; best.ksplit = ksp; }
           }
         }
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        append_plan_file(key, best, best_ms * 1e3f / 3);
         if (getenv("ECHO_GEMM_VERBOSE"))
           fprintf(stderr, "[echo] gemm plan M=%d N=%d K=%d taps=%d swiglu=%d T=%d: cfg %d ksplit %d (%.1f us)\n", g.M, g.N, g.K, g.taps,
                   g.swiglu, (int)sizeof(U), best.cfg, best.ksplit, best_ms * 1e3f / 3);
@@ -370,7 +447,14 @@ struct Engine : EngineBase {
       CK(hipEventRecord(e.second, st));
       return ECHO_OK;
     }
-    CK(launch_gemm_nt<T>(g, st));
+    {
+      hipError_t le = launch_gemm_nt<T>(g, st);
+      if (le == hipErrorInvalidValue && !g.fp8 && (g.cfg != 0 || g.ksplit > 1)) {   // a listed plan this launch's tail cannot take
+        g.cfg = 0; g.ksplit = 1;
+        le = launch_gemm_nt<T>(g, st);
+      }
+      CK(le);
+    }
     return ECHO_OK;
   }
 
@@ -599,15 +683,16 @@ struct Engine : EngineBase {
       const float scale = 1.0f / sqrtf(128.0f);
       for (int i = 0; i < n; ++i) {
         const SegDesc& sg = *act[i];
-        const int groups = sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
-        const int per = sg.kv_mod ? sg.kv_mod : rows;
+        const bool shared1 = sg.kv_mod == 1;      // one kv row shared by every query row: a single group with batch stride 0
+        const int groups = shared1 ? 1 : sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
+        const int per = shared1 ? rows : sg.kv_mod ? sg.kv_mod : rows;
         for (int gidx = 0; gidx < groups; ++gidx) {
           const int r0 = gidx * per, nr = std::min(per, rows - r0);
           GemmArgs g = G(q + (long)r0 * S * q_ld, q_ld, sg.K + (sg.kv_mod ? 0 : (long)r0 * sg.k_row_stride), sg.k_ld,
                          (T*)(sc + (long)r0 * H * S * ld + off[i]), ld, S, wdt[i], 128);
           g.nbatch = nr * H; g.nbi = H;
           g.a_bo = (long)S * q_ld; g.a_bi = 128;
-          g.w_bo = sg.k_row_stride; g.w_bi = 128;
+          g.w_bo = shared1 ? 0 : sg.k_row_stride; g.w_bi = 128;
           g.c_bo = (long)H * S * ld; g.c_bi = (long)S * ld;
           g.acc_scale = scale;
           CKI(run(g, st));
@@ -616,8 +701,9 @@ struct Engine : EngineBase {
       CK(launch_softmax_f32(sc, ld, S, rows * H, tot, tot, biasrows, ld, H, causal ? 1 : 0, 0, st));
       for (int i = 0; i < n; ++i) {
         const SegDesc& sg = *act[i];
-        const int groups = sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
-        const int per = sg.kv_mod ? sg.kv_mod : rows;
+        const bool shared1 = sg.kv_mod == 1;
+        const int groups = shared1 ? 1 : sg.kv_mod ? (rows + sg.kv_mod - 1) / sg.kv_mod : 1;
+        const int per = shared1 ? rows : sg.kv_mod ? sg.kv_mod : rows;
         for (int gidx = 0; gidx < groups; ++gidx) {
           const int r0 = gidx * per, nr = std::min(per, rows - r0);
           T* o = out + (long)r0 * S * o_ld;
@@ -625,7 +711,7 @@ struct Engine : EngineBase {
                          sg.vt_ld, o, o_ld, S, 128, wdt[i]);
           g.nbatch = nr * H; g.nbi = H;
           g.a_bo = (long)H * S * ld; g.a_bi = (long)S * ld;
-          g.w_bo = sg.vt_row_stride; g.w_bi = 128 * sg.vt_ld;
+          g.w_bo = shared1 ? 0 : sg.vt_row_stride; g.w_bi = 128 * sg.vt_ld;
           g.c_bo = (long)S * o_ld; g.c_bi = 128;
           if (i > 0) { g.res = o; g.ldres = o_ld; g.res_bo = g.c_bo; g.res_bi = g.c_bi; }
           CKI(run(g, st));
@@ -788,7 +874,7 @@ struct Engine : EngineBase {
     if (!rope) return fail("rope table not set");
     const int ps = cfg.speaker_patch_size;
     if (Ts % ps) return fail("speaker latent length must be a multiple of the patch size");
-    kvB = B;
+    spkB = B;
     spk_nk.assign(nk, nk + B);
     int Se = 0;
     for (int b = 0; b < B; ++b) { if (nk[b] < 0 || nk[b] > Ts / ps) return fail("bad speaker nkeys"); Se = std::max(Se, nk[b]); }
@@ -830,9 +916,87 @@ struct Engine : EngineBase {
     const int n = max_layers < 0 ? L : std::min(max_layers, L);
     const long ld = (long)L * 2 * D;
     for (int l = 0; l < n; ++l) {
-      CK(launch_scale_2d<T>(b_kv_spk.as<T>() + (long)l * 2 * D, ld, kvB * spk_T, 2 * D, s, st));
+      CK(launch_scale_2d<T>(b_kv_spk.as<T>() + (long)l * 2 * D, ld, spkB * spk_T, 2 * D, s, st));
       // the transposed copy of V follows (same elementwise product, same rounding)
-      CK(launch_scale_2d<T>(b_vt_spk.as<T>() + (long)l * kvB * D * spk_vld, spk_vld, kvB * D, spk_T, s, st));
+      CK(launch_scale_2d<T>(b_vt_spk.as<T>() + (long)l * spkB * D * spk_vld, spk_vld, spkB * D, spk_T, s, st));
+    }
+    return ECHO_OK;
+  }
+
+  // Per-voice cache (the reference re-runs get_kv_cache_speaker for every chunk: handler.py:750-758,
+  // inference.py:333-340, model.py:615-621).  capture: device copy of the speaker K/V + Vᵀ of all layers as they stand
+  // (call it right after echo_encode_speaker, before any speaker-KV scaling); bind: copy it back as this context's speaker
+  // cache, bit-identical to a fresh encode, without running the 14-layer encoder or the 24 projections.
+  int voice_capture(VoiceSnap** out, hipStream_t st) override {
+    if (!out) return fail("null output");
+    std::unique_ptr<VoiceSnap> v(new VoiceSnap());
+    v->device = device; v->precision = cfg.precision; v->model_size = cfg.model_size; v->num_layers = cfg.num_layers;
+    v->B = spkB; v->T = spk_T; v->pad = spk_pad; v->vld = spk_vld; v->nk = spk_nk; v->has_bias = spk_has_bias; v->bias_ld = spk_bias_ld;
+    if (spkB < 1) return fail("no speaker cache to capture (call echo_encode_speaker first)");
+    if (spk_T > 0) {
+      const int D = cfg.model_size, L = cfg.num_layers;
+      v->kv_bytes = (size_t)spkB * spk_T * L * 2 * D * sizeof(T);
+      v->vt_bytes = (size_t)L * spkB * D * spk_vld * sizeof(T);
+      CK(v->kv.reserve(v->kv_bytes)); CK(v->vt.reserve(v->vt_bytes));
+      CK(hipMemcpyAsync(v->kv.p, b_kv_spk.p, v->kv_bytes, hipMemcpyDeviceToDevice, st));
+      CK(hipMemcpyAsync(v->vt.p, b_vt_spk.p, v->vt_bytes, hipMemcpyDeviceToDevice, st));
+      if (spk_has_bias) {
+        v->bias_bytes = (size_t)spkB * spk_bias_ld * sizeof(float);
+        CK(v->bias.reserve(v->bias_bytes));
+        CK(hipMemcpyAsync(v->bias.p, b_bias_spk.p, v->bias_bytes, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    *out = v.release();
+    return ECHO_OK;
+  }
+  int voice_bind(const VoiceSnap* v, hipStream_t st) override {
+    if (!dit_ready) return fail("echo_finalize_dit was not called");
+    if (!v) return fail("null voice");
+    if (v->device != device || v->precision != cfg.precision || v->model_size != cfg.model_size || v->num_layers != cfg.num_layers)
+      return fail("voice was captured from a different model / device / precision");
+    spkB = v->B; spk_T = v->T; spk_pad = v->pad; spk_vld = v->vld; spk_nk = v->nk; spk_has_bias = v->has_bias; spk_bias_ld = v->bias_ld;
+    if (spk_T > 0) {
+      const int D = cfg.model_size, L = cfg.num_layers;
+      CK(b_kv_spk.reserve((size_t)((long)spkB * spk_T + 256) * L * 2 * D * sizeof(T)));
+      CK(b_vt_spk.reserve(v->vt_bytes + 4096));
+      CK(hipMemcpyAsync(b_kv_spk.p, v->kv.p, v->kv_bytes, hipMemcpyDeviceToDevice, st));
+      CK(hipMemcpyAsync(b_vt_spk.p, v->vt.p, v->vt_bytes, hipMemcpyDeviceToDevice, st));
+      if (spk_has_bias) {
+        CK(b_bias_spk.reserve(v->bias_bytes));
+        CK(hipMemcpyAsync(b_bias_spk.p, v->bias.p, v->bias_bytes, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    return ECHO_OK;
+  }
+
+  size_t workspace_bytes() override {
+    size_t n = b_gemm_ws.cap + b_tune_c.cap + b_flush.cap + b_q8.cap + b_qs.cap;
+    for (DevBuf* b : all_bufs()) n += b->cap;
+    return n;
+  }
+  // grows every workspace a request of this geometry touches (B utterances per sampler call, S latents, Tt text tokens,
+  // Ts speaker latents, T_dac frames per DAC decode), so that the first request allocates nothing (SURVEY.md §8b "ownership")
+  int reserve_workspace(int B, int S, int Tt, int Ts, int T_dac) override {
+    const int D = cfg.model_size, L = cfg.num_layers;
+    if (B < 1 || 3 * B > MAXROWS || S < 1) return fail("bad workspace geometry");
+    if (dit_ready) {
+      CKI(reserve_dit_ws(3 * B * S, 3 * B, S));
+      CK(b_xstate.reserve((size_t)B * S * cfg.latent_size * sizeof(float)));
+      const long ld = (long)L * 2 * D;
+      if (Tt > 0) { CK(b_kv_text.reserve((size_t)((long)B * Tt + 256) * ld * sizeof(T))); CK(b_vt_text.reserve((size_t)L * B * D * rup(Tt, 64) * sizeof(T) + 4096)); }
+      const int Sk = Ts / std::max(1, cfg.speaker_patch_size);
+      if (Sk > 0) { CK(b_kv_spk.reserve((size_t)((long)B * Sk + 256) * ld * sizeof(T))); CK(b_vt_spk.reserve((size_t)L * B * D * rup(Sk, 64) * sizeof(T) + 4096)); }
+    }
+    if (dac_ready && T_dac > 0) {
+      long upf = 1;
+      for (int i = 0; i < cfg.dac_n_up; ++i) upf *= cfg.dac_up_factors[i];
+      const int C = cfg.dac_latent_dim;
+      long maxel = (long)T_dac * upf * std::max(C * 4, cfg.dac_decoder_dim);
+      long rows = (long)T_dac * upf;
+      for (auto& b : dblocks) { rows *= b.r; maxel = std::max(maxel, rows * b.co); }
+      const long PADF = 64L * std::max(cfg.dac_decoder_dim, 4 * C);
+      const size_t bytes = (size_t)(maxel + PADF + 128L * 4 * C) * sizeof(float);
+      CK(b_dacA.reserve(bytes)); CK(b_dacB.reserve(bytes)); CK(b_dacC.reserve(bytes));
     }
     return ECHO_OK;
   }
@@ -842,7 +1006,7 @@ struct Engine : EngineBase {
     const long ld = (long)L * 2 * D;
     DevBuf* kv = which == 0 ? &b_kv_text : which == 1 ? &b_kv_spk : &b_kv_lat;
     const int Tn = which == 0 ? text_T : which == 1 ? spk_T : lat_T;
-    const int B = which == 2 ? latB : kvB;
+    const int B = which == 2 ? latB : which == 1 ? spkB : kvB;
     if (Bo) *Bo = B;
     if (To) *To = Tn;
     if (!k || !v || Tn == 0) return ECHO_OK;
@@ -877,7 +1041,7 @@ struct Engine : EngineBase {
       if (in && use_latent && lat_T > 0) nl = std::min(lat_T, (start_pos + cfg.speaker_patch_size - 1) / cfg.speaker_patch_size);
       host_nk[1 * MAXROWS + r] = nl;
       host_nk[2 * MAXROWS + r] = (in && text_T > 0 && (!ton || ton[r])) ? text_nk[b] : 0;
-      host_nk[3 * MAXROWS + r] = (in && spk_T > 0 && (!son || son[r])) ? spk_nk[b] : 0;
+      host_nk[3 * MAXROWS + r] = (in && spk_T > 0 && spkB > 0 && (!son || son[r])) ? spk_nk[b % spkB] : 0;
     }
   }
 
@@ -938,10 +1102,10 @@ struct Engine : EngineBase {
         sg[2].Vt = b_vt_text.as<T>() + (long)l * kvB * D * text_vld; sg[2].vt_ld = text_vld; sg[2].vt_row_stride = (long)D * text_vld;
         if (text_has_bias) { sg[2].bias = b_bias_text.as<float>(); sg[2].bias_ld = text_bias_ld; }
       }
-      sg[3].which = 3; sg[3].maxk = max_spk; sg[3].kv_mod = kvB;
+      sg[3].which = 3; sg[3].maxk = max_spk; sg[3].kv_mod = spkB;
       if (max_spk > 0) {
         sg[3].K = b_kv_spk.as<T>() + (long)l * 2 * D; sg[3].k_ld = kvld; sg[3].k_row_stride = (long)spk_T * kvld;
-        sg[3].Vt = b_vt_spk.as<T>() + (long)l * kvB * D * spk_vld; sg[3].vt_ld = spk_vld; sg[3].vt_row_stride = (long)D * spk_vld;
+        sg[3].Vt = b_vt_spk.as<T>() + (long)l * spkB * D * spk_vld; sg[3].vt_ld = spk_vld; sg[3].vt_row_stride = (long)D * spk_vld;
         if (spk_has_bias) { sg[3].bias = b_bias_spk.as<float>(); sg[3].bias_ld = spk_bias_ld; }
       }
       CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st));
@@ -1020,6 +1184,7 @@ struct Engine : EngineBase {
                   const int32_t* son, float* v, hipStream_t st) override {
     if (!dit_ready) return fail("echo_finalize_dit was not called");
     if (rows < 1 || rows > MAXROWS || B < 1 || rows % B || B != kvB) return fail("bad rows/B");
+    if (spk_T > 0 && (spkB < 1 || kvB % spkB)) return fail("the speaker cache's batch size must divide the text cache's");
     const int M = rows * S;
     CKI(reserve_dit_ws(M, rows, S));
     CKI(compute_mod((const T*)temb, 1, st));
@@ -1038,6 +1203,7 @@ struct Engine : EngineBase {
     if (!dit_ready) return fail("echo_finalize_dit was not called");
     const int B = p->B, S = p->S, N = p->num_steps, Lz = cfg.latent_size;
     if (B != kvB || 3 * B > MAXROWS || S < 1 || N < 1) return fail("bad sampler params");
+    if (spk_T > 0 && (spkB < 1 || kvB % spkB)) return fail("the speaker cache's batch size must divide the text cache's");
     const int rows3 = 3 * B;
     CKI(reserve_dit_ws(rows3 * S, rows3, S));
     CK(b_xstate.reserve((size_t)B * S * Lz * sizeof(float)));
@@ -1061,14 +1227,14 @@ struct Engine : EngineBase {
     e.x = xs; e.v = b_vout.p; e.ldv = 128; e.xin = b_xin.p; e.ld_xin = lat_pad;
     e.B = B; e.S = S; e.L = Lz; e.R = 1;
     e.R_next = p->steps[0].has_cfg ? 3 : 1;
-    e.init_scale = p->init_scale == 0.0f ? 1.0f : p->init_scale;
+    e.init = 1; e.init_scale = p->init_scale;      // x_t = x_t * truncation_factor (inference.py:478-479); 1.0 = none, 0.0 is honoured
     CK(launch_euler<T>(e, st));
     for (int i = 0; i < N; ++i) {
       const echo_step& sp = p->steps[i];
       const int rows = sp.has_cfg ? rows3 : B;
       CKI(forward_rows(rows, B, S, p->start_pos, p->use_latent != 0, b_mod.as<T>() + (long)i * modstride, st));
       if (sp.kv_unscale_after) CKI(scale_speaker_kv(1.0f / p->kv_scale, p->kv_max_layers, st));
-      e.init_scale = 0.0f;
+      e.init = 0;
       e.R = sp.has_cfg ? 3 : 1;
       e.R_next = (i + 1 < N && p->steps[i + 1].has_cfg) ? 3 : 1;
       e.s_text = p->cfg_scale_text; e.s_spk = p->cfg_scale_speaker;
@@ -1270,6 +1436,15 @@ struct Engine : EngineBase {
     return dac_run(lat, nullptr, Tn, latent_scale, wav, st);
   }
   int dac_decode_zq(const float* z, int Tn, float* wav, hipStream_t st) override { return dac_run(nullptr, z, Tn, 1.0f, wav, st); }
+  // streaming decode: the post_module transformer sees all Tn frames (its stacked causal windows reach back
+  // 8 x 127 frames), the convolutional stack (95 % of the FLOPs) only runs on frames f0.. and wav receives (Tn - f0) * hop * up
+  // samples; every conv is causal (autoencoder.py:264-331), so the samples further than the stack's receptive field (< 10
+  // frames) from frame f0 equal the whole-utterance decode.  The caller drops the context frames.
+  int dac_decode_tail(const float* lat, int Tn, int f0, float latent_scale, float* wav, hipStream_t st) override {
+    if (!pca_set) return fail("echo_set_pca was not called");
+    if (f0 < 0 || f0 >= Tn) return fail("bad first frame");
+    return dac_run(lat, nullptr, Tn, latent_scale, wav, st, f0);
+  }
 
   // WindowLimitedTransformer layers on channels-last x (Tn, C), in place; scratch: xn_buf, ao_buf (>= Tp*C + Tp*ff floats
   // and Tn*C floats).  autoencoder.py:786-802, 590-626, 663-717.  The final RMSNorm is applied by the caller.
@@ -1546,7 +1721,7 @@ struct Engine : EngineBase {
   }
 
   // lat: (T, latent) latents (PCA applied here)  OR  zq: (T, C) channels-last quantizer output
-  int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st) {
+  int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st, int f0 = 0) {
     if (!dac_ready) return fail("echo_finalize_dac was not called");
     if (!ae_rope || Tn > ae_rope_npos) return fail("ae rope table missing or too short");
     const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
@@ -1585,10 +1760,12 @@ struct Engine : EngineBase {
     CKI(dac_transformer(dpost, x, Tn, C, nh, hd, ff, cfg.dac_post_window, bufS, bufU, st));
     CK(launch_norm<float>(NORM_AE_RMS, x, C, bufS, C, Tn, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
     // ---- quantizer.upsample: [ConvT k=f s=f ; ConvNeXt] (autoencoder.py:427-435, 360-373)
-    float* cur = bufS;      // (rows, C)
+    // f0 > 0: only frames f0.. go through the convolutions; the first conv's causal taps then read the real frames in front
+    // of f0 (still in bufS), every later one the zero rows in front of its buffer
+    float* cur = bufS + (long)f0 * C;      // (rows, C)
     float* other = bufY;
     float* third = bufU;
-    long rows = Tn;
+    long rows = Tn - f0;
     for (auto& U : dups) {
       { GemmArgs g = FG(cur, C, U.w, C, other, (long)U.f * C, rows, U.f * C, C); g.bias = U.b; g.vec_mod = C; CKI(frun(g, st)); }
       rows *= U.f;
@@ -1777,6 +1954,35 @@ int echo_dac_hop(echo_ctx* ctx) {
 int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out) {
   return ctx ? ctx->eng->debug_get_kv(which, layer, k_out, v_out, B_out, T_out) : ECHO_ERR;
 }
+// ---- per-voice cache, streaming decode, workspace sizing
+struct echo_voice { VoiceSnap* v; };
+int echo_voice_capture(echo_ctx* ctx, echo_voice** out, void* stream) {
+  if (!ctx || !out) return ECHO_ERR;
+  VoiceSnap* v = nullptr;
+  const int r = ctx->eng->voice_capture(&v, (hipStream_t)stream);
+  if (r != ECHO_OK) return r;
+  *out = new echo_voice{v};
+  return ECHO_OK;
+}
+int echo_voice_bind(echo_ctx* ctx, const echo_voice* voice, void* stream) {
+  return ctx && voice ? ctx->eng->voice_bind(voice->v, (hipStream_t)stream) : ECHO_ERR;
+}
+int64_t echo_voice_bytes(const echo_voice* voice) {
+  return voice && voice->v ? (int64_t)(voice->v->kv_bytes + voice->v->vt_bytes + voice->v->bias_bytes) : 0;
+}
+void echo_voice_destroy(echo_voice* voice) {
+  if (!voice) return;
+  if (voice->v) { (void)hipSetDevice(voice->v->device); delete voice->v; }
+  delete voice;
+}
+int echo_dac_decode_tail(echo_ctx* ctx, const float* latent, int T, int first_frame, float latent_scale, float* wav_out, void* stream) {
+  return ctx ? ctx->eng->dac_decode_tail(latent, T, first_frame, latent_scale, wav_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int64_t echo_workspace_bytes(echo_ctx* ctx) { return ctx ? (int64_t)ctx->eng->workspace_bytes() : 0; }
+int echo_reserve_workspace(echo_ctx* ctx, int B, int S, int Tt, int Ts, int T_dac) {
+  return ctx ? ctx->eng->reserve_workspace(B, S, Tt, Ts, T_dac) : ECHO_ERR;
+}
+
 int echo_set_profiling(echo_ctx* ctx, int on) { if (!ctx) return ECHO_ERR; ctx->eng->profiling = on != 0; return ECHO_OK; }
 int echo_get_profile(echo_ctx* ctx, echo_profile* out) { if (!ctx || !out) return ECHO_ERR; *out = ctx->eng->prof; return ECHO_OK; }
 
@@ -1805,6 +2011,8 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
   g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3;
   g.fp8 = d->fp8; g.a_scale = d->a_scale; g.w_scale = d->w_scale;
+  g.qkv_mode = d->qkv_mode; g.qkv_D = d->qkv_D; g.qkv_S = d->qkv_S; g.rope_heads = d->rope_heads; g.pos0 = d->pos0; g.qk_eps = d->qk_eps;
+  g.qk_w = d->qk_w; g.rope = d->rope; g.vt = d->vt; g.vt_ld = d->vt_ld; g.vt_row_stride = d->vt_row_stride;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
 }
 int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,
@@ -1850,6 +2058,26 @@ int echo_op_transpose_heads(int dtype, const void* v, int64_t ldv, void* vt, int
   return op_status(dtype == ECHO_BF16
                        ? launch_transpose_heads<bf16_t>((const bf16_t*)v, ldv, (bf16_t*)vt, vt_ld, vt_b_stride, B, S, H, HD, st)
                        : launch_transpose_heads<float>((const float*)v, ldv, (float*)vt, vt_ld, vt_b_stride, B, S, H, HD, st));
+}
+
+// ---- on-device post-processing (postproc.hip)
+int echo_op_find_flattening_point(const float* latent, int64_t item_stride, int B, int T, int W, int window, float target, float std_threshold,
+                                  int32_t* out_dev, void* stream) {
+  return op_status(launch_flatten_point(latent, item_stride, B, T, W, window, target, std_threshold, out_dev, (hipStream_t)stream));
+}
+int echo_op_trailing_quiet(const float* const* chunks_host, const int64_t* lens_host, int n, int max_window, float threshold, int32_t* out_dev,
+                           void* stream) {
+  if (!chunks_host || !lens_host || n < 1 || n > ECHO_MAX_CHUNKS) return op_status(hipErrorInvalidValue);
+  long lens[ECHO_MAX_CHUNKS];
+  for (int i = 0; i < n; ++i) lens[i] = (long)lens_host[i];
+  return op_status(launch_trailing_quiet(chunks_host, lens, n, max_window, threshold, out_dev, (hipStream_t)stream));
+}
+int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_host, const int64_t* len_host, const int64_t* valid_host,
+                            const int32_t* overlap_host, int n, float* out_dev, int64_t total, void* stream) {
+  if (!src_host || !start_host || !len_host || !valid_host || !overlap_host || n < 1 || n > ECHO_MAX_CHUNKS) return op_status(hipErrorInvalidValue);
+  long st_[ECHO_MAX_CHUNKS], ln_[ECHO_MAX_CHUNKS], va_[ECHO_MAX_CHUNKS]; int ov_[ECHO_MAX_CHUNKS];
+  for (int i = 0; i < n; ++i) { st_[i] = (long)start_host[i]; ln_[i] = (long)len_host[i]; va_[i] = (long)valid_host[i]; ov_[i] = overlap_host[i]; }
+  return op_status(launch_assemble_chunks(src_host, st_, ln_, va_, ov_, n, out_dev, (long)total, (hipStream_t)stream));
 }
 
 }  // extern "C"

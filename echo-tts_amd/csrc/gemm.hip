@@ -1284,6 +1284,9 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
         g.snake_alpha || g.C2 || !g.store_main ||
         (g.qkv_mode && ((g.qkv_D & 255) || (g.vt_ld & 7))))
       return hipErrorInvalidValue;
+    // the per-lane part of a DMA source address is a 32-bit byte offset (row * pitch + chunk): refuse operands it cannot span
+    const long es = g.fp8 ? 1 : 2;
+    if ((long)(g.M - 1) * g.lda * es + 128 >= (1L << 32) || (long)(g.Npad - 1) * g.ldw * es + 128 >= (1L << 32)) return hipErrorInvalidValue;
   }
   if (g.fp8 && g.cfg != 5) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel only
   if (g.cfg == 5) {

@@ -158,9 +158,28 @@ def get_speaker_latent_and_mask(fish_ae: DAC, pca_state: PCAState, audio: torch.
     return speaker_latent, mask
 
 
+def find_flattening_points(latents: torch.Tensor, target_value: float = 0.0, window_size: int = 20, std_threshold: float = 0.05) -> List[int]:
+    """reference inference.py:288-296 for a batch (B, T, W) of device latents: ONE kernel launch (csrc/postproc.hip) and one
+    B-int read-back instead of up to 640 iterations x 2 host syncs per utterance."""
+    if latents.dim() == 2:
+        latents = latents.unsqueeze(0)
+    x = latents.detach().to(torch.float32).contiguous()
+    if not x.is_cuda:
+        raise L.EchoHipError("find_flattening_points needs device latents (the host version is find_flattening_point)")
+    B, T = x.shape[0], x.shape[1]
+    W = x[0, 0].numel()
+    out = torch.empty((B,), dtype=torch.int32, device=x.device)
+    L.check(L.load_library().echo_op_find_flattening_point(x.data_ptr(), T * W, B, T, W, int(window_size), float(target_value),
+                                                           float(std_threshold), out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+    return [int(v) for v in out.tolist()]
+
+
 def find_flattening_point(data: torch.Tensor, target_value: float = 0.0, window_size: int = 20, std_threshold: float = 0.05) -> int:
     """First frame i whose next `window_size` frames (zero padded) have std < threshold and |mean - target| < 0.1
-    (reference inference.py:288-296), evaluated with one cumulative-sum pass on the host instead of 640 syncs."""
+    (reference inference.py:288-296).  Device latents go through the HIP kernel (find_flattening_points); host tensors
+    (tests, tools) are evaluated with one cumulative-sum pass instead of the reference's per-frame loop."""
+    if data.is_cuda:
+        return find_flattening_points(data.unsqueeze(0), target_value, window_size, std_threshold)[0]
     x = data.detach().to("cpu", torch.float64)
     n, width = x.shape[0], x[0].numel()
     flat = torch.cat([x.reshape(n, -1), torch.zeros(window_size, width, dtype=torch.float64)])
@@ -269,15 +288,19 @@ def sample_euler_cfg_independent_guidances(
     speaker_kv_min_t: float | None,
     sequence_length: int | None = None,
     x_init: torch.Tensor | None = None,
+    speaker_kv=None,
 ) -> torch.Tensor:
-    """Drop-in for reference inference.py:427-517.  `x_init` (extension) replaces the RNG draw, for fixtures."""
+    """Drop-in for reference inference.py:427-517.  Extensions: `x_init` replaces the RNG draw (fixtures); `speaker_kv`
+    (a model.VoiceHandle from the per-voice cache) is bound instead of re-running get_kv_cache_speaker, `speaker_latent` is
+    then ignored.  A speaker latent with batch 1 next to B text rows is one voice shared by every row (the handler's chunks of
+    one request, handler.py:747-759): its KV is encoded once and addressed with stride 0."""
     if sequence_length is None:
         sequence_length = 640
     device = model.device
     B = text_input_ids.shape[0]
     steps, temb = build_schedule(model, num_steps, cfg_min_t, cfg_max_t, rescale_k, rescale_sigma, speaker_kv_scale, speaker_kv_min_t)
     model.get_kv_cache_text(text_input_ids, text_mask)
-    kv_spk = model.get_kv_cache_speaker(speaker_latent, speaker_mask)
+    kv_spk = model.bind_voice(speaker_kv) if speaker_kv is not None else model.get_kv_cache_speaker(speaker_latent, speaker_mask)
     if speaker_kv_scale is not None:
         _multiply_kv_cache(kv_spk, speaker_kv_scale, speaker_kv_max_layers)
     if x_init is None:

@@ -96,6 +96,31 @@ class KVHandle:
         return self.model._read_kv(which, i)
 
 
+class VoiceHandle:
+    """A reference voice as the sampler consumes it: the speaker encoder output projected to the K / V of all EchoDiT layers
+    (model.py:615-621), held on the device outside any engine context.  `EchoDiT.capture_voice()` makes one after
+    `get_kv_cache_speaker`; `EchoDiT.bind_voice()` installs it into a context (same model / precision / device) without
+    running the encoder again — bit-identical to a fresh encode (tests/test_gpu_engine.py)."""
+
+    def __init__(self, lib, ptr, mask: Optional[torch.Tensor], batch: int):
+        self._lib, self._ptr, self.mask, self.batch = lib, ptr, mask, batch
+
+    @property
+    def nbytes(self) -> int:
+        return int(self._lib.echo_voice_bytes(self._ptr)) if self._ptr else 0
+
+    def close(self) -> None:
+        if getattr(self, "_ptr", None):
+            self._lib.echo_voice_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class EchoDiT:
     """model.py:472 `EchoDiT`, inference only, executed by libechohip."""
 
@@ -213,8 +238,30 @@ class EchoDiT:
         nk_arr = (C.c_int32 * B)(*nk)
         L.check(self._lib.echo_encode_speaker(self._ctx, lat.data_ptr(), bias_dev.data_ptr() if bias_dev is not None else None,
                                               nk_arr, B, Ts, self._stream()), self._ctx)
-        self._kvB = B
+        if not self._kvB:
+            self._kvB = B
         return KVHandle(self, "speaker", kmask, B)
+
+    # ------------------------------------------------------------------ per-voice cache
+    def capture_voice(self, kv_cache_speaker: KVHandle) -> VoiceHandle:
+        """Snapshot of the speaker cache `get_kv_cache_speaker` just built (call before any speaker-KV scaling)."""
+        ptr = C.c_void_p()
+        L.check(self._lib.echo_voice_capture(self._ctx, C.byref(ptr), self._stream()), self._ctx)
+        return VoiceHandle(self._lib, ptr, kv_cache_speaker.mask, kv_cache_speaker.batch)
+
+    def bind_voice(self, voice: VoiceHandle) -> KVHandle:
+        """Install a captured voice as this context's speaker cache; the returned handle is what `get_kv_cache_speaker` returns."""
+        if not voice._ptr:
+            raise L.EchoHipError("voice handle was closed")
+        L.check(self._lib.echo_voice_bind(self._ctx, voice._ptr, self._stream()), self._ctx)
+        return KVHandle(self, "speaker", voice.mask, voice.batch)
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.echo_workspace_bytes(self._ctx))
+
+    def reserve_workspace(self, batch: int, sequence_length: int = 640, text_tokens: int = 768, speaker_latents: int = 6400) -> None:
+        """Grow KV caches and workspaces for this request geometry now, so that the first request allocates nothing."""
+        L.check(self._lib.echo_reserve_workspace(self._ctx, int(batch), int(sequence_length), int(text_tokens), int(speaker_latents), 0), self._ctx)
 
     def get_kv_cache_latent(self, prefix_latent: torch.Tensor, n_latents: Optional[int] = None) -> KVHandle:
         """`n_latents`: how many leading prefix latents can ever be attended (start_pos rounded up to the patch);
@@ -240,7 +287,7 @@ class EchoDiT:
             raise NotImplementedError("all rows of one forward must share the timestep (the sampler always does)")
         temb = timestep_embedding(tt[:1].to(self._dtype), self.config.timestep_embed_size).to(self._device).contiguous()
         ton = self._row_switch(text_mask, kv_cache_text.mask, rows, B, 1)
-        son = self._row_switch(speaker_mask, kv_cache_speaker.mask, rows, B, self.config.speaker_patch_size)
+        son = self._row_switch(speaker_mask, kv_cache_speaker.mask, rows, kv_cache_speaker.batch, self.config.speaker_patch_size)
         xin = x.to(self._device, self._dtype).contiguous()
         out = torch.empty((rows, S, Lz), dtype=torch.float32, device=self._device)
         L.check(self._lib.echo_dit_forward(self._ctx, xin.data_ptr(), temb.data_ptr(), rows, B, S, int(start_pos or 0),

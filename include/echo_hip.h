@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 3
+#define ECHO_ABI_VERSION 4
 
 typedef struct echo_ctx echo_ctx;
 
@@ -92,6 +92,23 @@ int echo_encode_latent_prefix(echo_ctx* ctx, const void* latent, int B, int n_la
 /* inference.py:408-414 _multiply_kv_cache on the speaker cache (K and V of layers < max_layers) */
 int echo_scale_speaker_kv(echo_ctx* ctx, float scale, int max_layers, void* stream);
 
+/* Per-voice cache.  The reference re-encodes the reference voice for every text chunk (handler.py:750-758 ->
+ * inference.py:333-340 -> model.py:615-621).  echo_voice_capture copies the context's current speaker cache (K / V / V^T of all
+ * layers, key counts, optional key bias) into an object owned by the caller; echo_voice_bind makes it the context's speaker
+ * cache again (device copy, bit-identical to a fresh echo_encode_speaker) on any context of the same model, precision and
+ * device.  The speaker cache may have batch size 1 while the text cache has B: every row then shares the one voice. */
+typedef struct echo_voice echo_voice;
+int echo_voice_capture(echo_ctx* ctx, echo_voice** out, void* stream);
+int echo_voice_bind(echo_ctx* ctx, const echo_voice* voice, void* stream);
+int64_t echo_voice_bytes(const echo_voice* voice);
+void echo_voice_destroy(echo_voice* voice);
+
+/* SURVEY.md §8b "echo_workspace_bytes": device bytes of KV caches + workspaces the context currently holds, and a call that
+ * grows them for a request geometry up front (B utterances per sampler call, S latents, Tt text tokens, Ts speaker latents,
+ * T_dac frames per decode) so that the first request allocates nothing. */
+int64_t echo_workspace_bytes(echo_ctx* ctx);
+int echo_reserve_workspace(echo_ctx* ctx, int B, int S, int Tt, int Ts, int T_dac);
+
 /* model.py:563-604 EchoDiT.forward for `rows` = R*B rows that share one timestep.
  * x (rows*S, latent) of T; temb (1, timestep_embed) of T (model.py:27-43 evaluated by the host);
  * row r uses text/speaker KV of batch item r % B; row_text_on/row_spk_on (host, rows) switch the
@@ -111,7 +128,7 @@ typedef struct {
   int B, S, num_steps;
   int start_pos, use_latent;     /* blockwise: inference_blockwise.py:91-94 */
   float cfg_scale_text, cfg_scale_speaker;
-  float init_scale;              /* truncation_factor or 1 (inference.py:478-479) */
+  float init_scale;              /* truncation_factor (inference.py:478-479: x_t = x_t * factor; 0.0 is honoured), 1 when None */
   float kv_scale; int kv_max_layers;   /* used by kv_unscale_after steps: multiply by 1/kv_scale */
   const echo_step* steps;        /* host, num_steps entries */
   const void* temb;              /* device, (num_steps, timestep_embed) of T */
@@ -127,6 +144,12 @@ int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* 
 int echo_dac_decode(echo_ctx* ctx, const float* latent, int T, float latent_scale, float* wav_out, void* stream);
 /* autoencoder.py:1128-1132 DAC.decode_zq alone: z (T, dac_latent_dim) fp32 CHANNELS-LAST (= z_q[b].T) -> wav (T * hop). */
 int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, void* stream);
+/* Streaming decode (reference: every conv of autoencoder.py:264-331 is causal, gradio_app.py:43 decodes whole
+ * utterances): latent (T, latent_size) fp32 are ALL frames generated so far; the window-limited post_module transformer
+ * runs over all of them, the convolutional stack only over frames first_frame.. ; wav_out receives (T - first_frame) * 2048
+ * samples.  Samples further than the stack's receptive field (< 10 frames) behind first_frame equal the
+ * whole-utterance decode; the caller (DACStream in autoencoder.py) discards that context. */
+int echo_dac_decode_tail(echo_ctx* ctx, const float* latent, int T, int first_frame, float latent_scale, float* wav_out, void* stream);
 /* inference.py:86-99 PCAState: w = pca_components transposed, (dac_latent_dim, latent_size) row-major fp32; mean (dac_latent_dim). */
 int echo_set_pca(echo_ctx* ctx, const float* w, const float* mean, int on_device, void* stream);
 int echo_dac_hop(echo_ctx* ctx);
@@ -157,6 +180,12 @@ typedef struct {
   int split3;                    /* fp32 only: 3 x bf16 MFMA per product (hi/lo operand splitting), ~1e-5 relative error */
   int fp8;                       /* dtype ECHO_BF16, cfg 5 only: A and W are e4m3 bytes, y = acc * a_scale[m] * w_scale[n]; K % 128 == 0 */
   const float* a_scale; const float* w_scale;
+  /* fused QKV(G) tail (model.py:217-232): the N axis is [q | k | v | gate] x qkv_D; q and k get the per-head RMSNorm (qk_w =
+   * [q_norm | k_norm], each qkv_D, eps qk_eps) and interleaved-pair RoPE on heads < rope_heads at position pos0 + (m % qkv_S)
+   * (rope: (npos, 64) float2 cos/sin); v is written transposed to vt[(m / qkv_S)][h * 128 + d][m % qkv_S] (pitches vt_ld,
+   * vt_row_stride in elements); gate is stored as is.  cfg 0-5 only, qkv_D % 256 == 0. */
+  int qkv_mode, qkv_D, qkv_S, rope_heads, pos0; float qk_eps;
+  const void* qk_w; const void* rope; void* vt; int64_t vt_ld, vt_row_stride;
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 /* bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (amax / 448): the operand format of the fp8 GEMM */
@@ -185,6 +214,20 @@ int echo_op_headnorm_rope(int dtype, void* x, int64_t ldx, int64_t t_stride, int
                           void* stream);
 int echo_op_transpose_heads(int dtype, const void* v, int64_t ldv, void* vt, int64_t vt_ld, int64_t vt_b_stride, int B, int S,
                             int H, int HD, void* stream);
+
+/* ---- on-device post-processing; `*_host` arguments are host arrays of n <= 64 entries ----
+ * inference.py:288-296 find_flattening_point for B latents (T, W) fp32 (item_stride floats apart): out_dev[b] = first frame whose
+ * zero-extended `window` frames have unbiased std < std_threshold and |mean - target| < 0.1, T if none. */
+int echo_op_find_flattening_point(const float* latent, int64_t item_stride, int B, int T, int W, int window, float target,
+                                  float std_threshold, int32_t* out_dev, void* stream);
+/* handler.py:199-211: out_dev[c] = number of trailing samples below `threshold` among the last min(len, max_window) of chunk c */
+int echo_op_trailing_quiet(const float* const* chunks_host, const int64_t* lens_host, int n, int max_window, float threshold,
+                           int32_t* out_dev, void* stream);
+/* handler.py:126-170 crossfade_chunks over chunks already trimmed / zero-extended by handler.py:213-232: chunk i supplies
+ * len[i] samples from output position start[i] (the first valid[i] from src[i], zeros after), overlapping chunk i + 1 by
+ * overlap[i] samples mixed as result * linspace(1,0,n) + next * linspace(0,1,n). */
+int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_host, const int64_t* len_host, const int64_t* valid_host,
+                            const int32_t* overlap_host, int n, float* out_dev, int64_t total, void* stream);
 
 /* test hook: copy one DiT layer's cached K and V (which: 0 text, 1 speaker, 2 latent) as fp32 (B, T, model_size);
  * K is post-k_norm(/RoPE), V as projected.  Synchronous.  *B_out / *T_out receive the cache geometry. */

@@ -38,7 +38,7 @@ def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
 def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
          nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
          vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
-         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None):
+         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None, qkv=None):
     d = L.EchoGemmDesc()
     es = A.element_size()
     d.A = A.data_ptr() + a_offset_elems * es
@@ -59,6 +59,9 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     d.cfg, d.ksplit, d.split3 = cfg, ksplit, split3
     if a_scale is not None:   # e4m3 operands: A / W are uint8 tensors, the output C decides the dtype code
         d.fp8, d.a_scale, d.w_scale = 1, a_scale.data_ptr(), w_scale.data_ptr()
+    if qkv is not None:       # fused QKV(G) tail: dict(D, S, rope_heads, pos0, eps, qk_w, rope, vt, vt_ld, vt_row_stride)
+        d.qkv_mode, d.qkv_D, d.qkv_S, d.rope_heads, d.pos0, d.qk_eps = 1, qkv["D"], qkv["S"], qkv["rope_heads"], qkv.get("pos0", 0), qkv["eps"]
+        d.qk_w, d.rope, d.vt, d.vt_ld, d.vt_row_stride = qkv["qk_w"].data_ptr(), qkv["rope"].data_ptr(), qkv["vt"].data_ptr(), qkv["vt_ld"], qkv["vt_row_stride"]
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     elif ksplit > 1:
@@ -100,3 +103,54 @@ def quant_rows_fp8(x: torch.Tensor):
     s = torch.empty((rows,), dtype=torch.float32, device=x.device)
     L.check(lib().echo_op_quant_rows_fp8(x.data_ptr(), x.stride(0), q.data_ptr(), K, s.data_ptr(), rows, K, stream()))
     return q, s
+
+
+class FlushAlloc:
+    """A dedicated hipMalloc whose payload ENDS exactly at the end of the allocation (sizes rounded up to 2 MiB, the granule the
+    driver maps): a kernel that reads or writes even one byte past the operand touches the next, normally unmapped, page and
+    faults deterministically instead of silently reading a neighbour.  Duck-types the two tensor methods gemm() uses."""
+
+    GRAN = 2 << 20
+
+    def __init__(self, src: torch.Tensor):
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipFree.argtypes = [C.c_void_p]
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        src = src.contiguous()
+        self.nbytes = src.numel() * src.element_size()
+        self.alloc = (self.nbytes + self.GRAN - 1) // self.GRAN * self.GRAN
+        base = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(base), self.alloc) == 0
+        self._base = base.value
+        self._ptr = self._base + self.alloc - self.nbytes
+        assert self._ptr % 16 == 0, "payload must stay 16-byte aligned"
+        torch.cuda.synchronize()
+        assert self._hip.hipMemset(self._base, 0, self.alloc) == 0
+        assert self._hip.hipMemcpy(self._ptr, src.data_ptr(), self.nbytes, 3) == 0     # hipMemcpyDeviceToDevice
+        self.shape, self.dtype, self._es = tuple(src.shape), src.dtype, src.element_size()
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def element_size(self) -> int:
+        return self._es
+
+    def to_tensor(self) -> torch.Tensor:
+        out = torch.empty(self.shape, dtype=self.dtype, device=DEV)
+        torch.cuda.synchronize()
+        assert self._hip.hipMemcpy(out.data_ptr(), self._ptr, self.nbytes, 3) == 0
+        return out
+
+    def free(self):
+        if self._base:
+            torch.cuda.synchronize()
+            self._hip.hipFree(self._base)
+            self._base = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -345,13 +345,23 @@ def test_c1_full_depth_fp32_against_oracle():
     assert eb < 1.5 * eref + 1e-3, (eb, eref)
 
 
-def test_c2_shape_full_depth_cfg_fp32_against_oracle():
-    """BASELINE config C2's SHAPES at full size with CFG on: 24-layer EchoDiT, S = 640, text of 436 tokens padded to 768,
-    speaker reference of 2560 latents (640 keys), cfg_text 3 / cfg_speaker 8 — 3 of C2's 40 Euler steps, of which the first two
-    are 3-row CFG steps (t = 0.999, 0.666 >= 0.5) and the last a 1-row step; the CPU oracle needs ~20 s per step.  The fp32
-    engine must meet the north-star latent tolerance against the fp32 oracle on the same noise."""
+C2_KW = dict(cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_min_t=0.5, cfg_max_t=1.0, truncation_factor=None,
+             rescale_k=None, rescale_sigma=None, speaker_kv_scale=None, speaker_kv_max_layers=None, speaker_kv_min_t=None)
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """Full-size EchoDiT (24 layers, d = 2048; 14-layer encoders) on seeded weights: the fp32 parity engine, the bf16 production
+    engine (the one bench.py times) and the weights themselves for the oracle; built once for the C2 / C3 tests below."""
     cfg = R.DiTConfig()
     w = R.make_dit_weights(cfg, seed=0, with_blockwise=False)
+    wb = {k: v.bfloat16() for k, v in w.items()}
+    return {"cfg": cfg, "w": w, "wb": wb,
+            "f32": E.EchoDiT(cfg, w, dtype=torch.float32, device=DEV),
+            "bf16": E.EchoDiT(cfg, wb, dtype=torch.bfloat16, device=DEV)}
+
+
+def _c2_inputs():
     g = torch.Generator().manual_seed(1234)
     ids = torch.zeros((1, 768), dtype=torch.int32)
     ids[0, 1:436] = torch.randint(32, 127, (435,), generator=g, dtype=torch.int32)
@@ -360,15 +370,122 @@ def test_c2_shape_full_depth_cfg_fp32_against_oracle():
     spk = torch.randn((1, 2560, 80), generator=g)
     smask = torch.ones((1, 2560), dtype=torch.bool)
     x0 = torch.randn((1, 640, 80), generator=torch.Generator().manual_seed(0))
-    kw = dict(num_steps=3, cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_min_t=0.5, cfg_max_t=1.0, truncation_factor=None,
-              rescale_k=None, rescale_sigma=None, speaker_kv_scale=None, speaker_kv_max_layers=None, speaker_kv_min_t=None)
+    return ids, tmask, spk, smask, x0
+
+
+def _eager_gpu_bf16_vs_fp32(fs, spk, smask, ids, tmask, x0, S, kw):
+    """The reference's own bf16 noise floor at this shape: PyTorch-ROCm eager (the oracle's torch ops on the MI355X) in bf16
+    against the same ops in fp32, same weights and noise (SURVEY.md §A.4 measured it on the CPU at small sizes)."""
+    dev = lambda t: t.to(DEV)
+    wf = {k: v.to(DEV) for k, v in fs["w"].items()}
+    a = R.sample_euler(wf, fs["cfg"], torch.float32, dev(spk), dev(smask), dev(ids), dev(tmask), rng_seed=0, sequence_length=S, x_init=dev(x0), **kw)
+    del wf
+    wb = {k: v.to(DEV) for k, v in fs["wb"].items()}
+    b = R.sample_euler(wb, fs["cfg"], torch.bfloat16, dev(spk), dev(smask), dev(ids), dev(tmask), rng_seed=0, sequence_length=S, x_init=dev(x0), **kw)
+    del wb
+    torch.cuda.empty_cache()
+    return a.cpu(), b.cpu()
+
+
+def test_c2_shape_full_depth_cfg_fp32_and_bf16_against_oracle(full_size):
+    """BASELINE config C2's SHAPES at full size with CFG on: 24-layer EchoDiT, S = 640, text of 436 tokens padded to 768,
+    speaker reference of 2560 latents (640 keys), cfg_text 3 / cfg_speaker 8 - 3 of C2's 40 Euler steps, of which the first two
+    are 3-row CFG steps (t = 0.999, 0.666 >= 0.5) and the last a 1-row step; the CPU oracle needs ~20 s per step.
+    * fp32 engine vs the fp32 CPU oracle on the same noise: the north-star latent tolerance (1e-3 RMS);
+    * bf16 engine - gemm_pp_kernel, attn_kernel<bf16>, the fused QKV tail at M = 1920 / 640, i.e. the production kernels - vs
+      the same fp32 oracle: no farther than 1.5 x PyTorch's own bf16-vs-fp32 distance at this shape (+1e-3), where PyTorch's
+      bf16 run is the oracle's torch ops executed eagerly on the MI355X (the "vendored PyTorch path" of the north star)."""
+    fs = full_size
+    ids, tmask, spk, smask, x0 = _c2_inputs()
+    kw = dict(C2_KW, num_steps=3)
     torch.set_num_threads(16)
-    want = R.sample_euler(w, cfg, torch.float32, spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
-    m = E.EchoDiT(cfg, w, dtype=torch.float32, device=DEV)
-    got = E.sample_euler_cfg_independent_guidances(m, spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
+    want = R.sample_euler(fs["w"], fs["cfg"], torch.float32, spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
+    got = E.sample_euler_cfg_independent_guidances(fs["f32"], spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
     e = rms(got, want)
     print(f"C2 shapes, full depth, 3 steps with CFG: fp32 engine rms {e:.3e} vs fp32 oracle (latent rms {U.rms(want):.3f})")
     assert e < LAT_TOL, (e, U.rms(want))
+    gotb = E.sample_euler_cfg_independent_guidances(fs["bf16"], spk, smask, ids, tmask, rng_seed=0, sequence_length=640, x_init=x0, **kw)
+    ea, eb_ref = _eager_gpu_bf16_vs_fp32(fs, spk, smask, ids, tmask, x0, 640, kw)
+    eref = rms(eb_ref, want)
+    eb = rms(gotb, want)
+    print(f"C2 shapes: bf16 engine rms {eb:.3e} vs fp32 oracle; PyTorch-ROCm eager bf16 vs fp32 oracle {eref:.3e}; eager fp32 on the GPU vs "
+          f"CPU oracle {rms(ea, want):.3e}; bf16 engine vs eager bf16 {rms(gotb, eb_ref):.3e}")
+    assert bool(torch.isfinite(gotb).all())
+    assert eb < 1.5 * eref + 1e-3, (eb, eref)
+
+
+def test_bench_workload_batch8_rows_match_single_fp32_calls(golden, full_size):
+    """The exact workload bench.py times (BASELINE C2 / C3 on one GPU): EIGHT utterances through one bf16 sampler call at full
+    depth - M = 15360 GEMM rows in the CFG steps (up to 7.5 output tiles per workgroup of the persistent kernel), 24-row
+    attention launches, one reference voice shared by all rows - with the mixed text lengths of text_presets.txt (token counts
+    of the first eight presets; the texts themselves stay in the reference).  4 Euler steps = 2 CFG steps + 2 plain ones.
+    Each row must match a SINGLE-utterance call of the fp32 parity engine (itself pinned to the oracle above) within the bf16
+    budget of that shape, the batched call must be bit-reproducible, and it must equal the bf16 engine's own single calls to
+    within the same budget (another batch shape means other tile plans, i.e. other rounding points)."""
+    fs = full_size
+    lens = golden["__meta__"]["host"]["preset_token_lengths"][:8]
+    B, S = 8, 640
+    g = torch.Generator().manual_seed(77)
+    ids = torch.zeros((B, 768), dtype=torch.int32)
+    tmask = torch.zeros((B, 768), dtype=torch.bool)
+    for b, n in enumerate(lens):
+        ids[b, 1:n] = torch.randint(32, 127, (n - 1,), generator=g, dtype=torch.int32)
+        tmask[b, :n] = True
+    spk = torch.randn((1, 2560, 80), generator=g)
+    smask = torch.ones((1, 2560), dtype=torch.bool)
+    x0 = torch.randn((B, S, 80), generator=g)
+    kw = dict(C2_KW, num_steps=4)
+    run = lambda m, sl: E.sample_euler_cfg_independent_guidances(m, spk, smask, ids[sl], tmask[sl], rng_seed=0, sequence_length=S,
+                                                                 x_init=x0[sl], **kw).cpu()
+    all8 = run(fs["bf16"], slice(0, B))
+    again = run(fs["bf16"], slice(0, B))
+    assert torch.equal(all8, again), "the batched bf16 sampler call is not bit-reproducible"
+    assert bool(torch.isfinite(all8).all())
+    # the reference's own bf16 noise floor at this shape, on row 0's inputs (PyTorch-ROCm eager bf16 vs fp32)
+    ea, eb_ref = _eager_gpu_bf16_vs_fp32(fs, spk, smask, ids[:1], tmask[:1], x0[:1], S, kw)
+    eref = rms(eb_ref, ea)
+    worst, worst_self = 0.0, 0.0
+    for b in range(B):
+        ref = run(fs["f32"], slice(b, b + 1))
+        one = run(fs["bf16"], slice(b, b + 1))
+        e, es = rms(all8[b:b + 1], ref), rms(all8[b:b + 1], one)
+        worst, worst_self = max(worst, e), max(worst_self, es)
+        assert e < 1.5 * eref + 1e-3, (b, e, eref)
+        assert es < 1.5 * eref + 1e-3, (b, es, eref)
+        if b == 0:
+            assert rms(ref, ea) < LAT_TOL      # the fp32 engine agrees with eager fp32 on the GPU at this shape as well
+    print(f"batch 8 x full depth x 4 steps: worst row rms {worst:.3e} vs fp32 single calls, {worst_self:.3e} vs bf16 single calls; "
+          f"PyTorch-ROCm bf16 vs fp32 at this shape {eref:.3e}")
+
+
+def test_full_width_layer_rows_span_many_tiles(golden):
+    """One full-width layer (WIDE1: d = 2048 x 16 heads, encoders 1280 x 10) with 12 rows x 640 latents = 7680 GEMM rows (960 tiles
+    in the QKVG projection): bf16 engine vs fp32 engine on the same inputs, one forward; the fused QKV / SwiGLU / residual tails
+    of the ping-pong kernel at a multi-tile shape inside the engine, without the depth that blurs a single wrong tile."""
+    cfg = WIDE1
+    w = R.make_dit_weights(cfg, seed=0)
+    mf = E.EchoDiT(cfg, w, dtype=torch.float32, device=DEV)
+    mb = E.EchoDiT(cfg, {k: v.bfloat16() for k, v in w.items()}, dtype=torch.bfloat16, device=DEV)
+    gen = torch.Generator().manual_seed(5)
+    B, S = 4, 640
+    ids = torch.randint(1, 256, (B, 300), generator=gen, dtype=torch.int32)
+    tmask = torch.ones((B, 300), dtype=torch.bool)
+    tmask[1, 200:] = False
+    spk, smask = torch.randn((1, 512, 80), generator=gen), torch.ones((1, 512), dtype=torch.bool)
+    x = torch.randn((3 * B, S, 80), generator=gen)
+    tm3 = torch.cat([tmask, torch.zeros_like(tmask), tmask], 0)
+    sm1 = smask.expand(B, -1)
+    sm3 = torch.cat([sm1, sm1, torch.zeros_like(sm1)], 0)
+    outs = []
+    for m, dt in ((mf, torch.float32), (mb, torch.bfloat16)):
+        kvt, kvs = m.get_kv_cache_text(ids, tmask), m.get_kv_cache_speaker(spk, smask)
+        # t = 0.75 is exact in bf16: the reference's bf16 path rounds t before the timestep embedding (inference.py:489), and
+        # bf16(0.7) would move the embedding's phases by up to 0.8 rad - a property of the reference, not of a kernel
+        outs.append(m(x.to(dt), torch.full((3 * B,), 0.75).to(dt), tm3, sm3, _concat_kv_caches(kvt, kvt, kvt), kvs).float().cpu())
+    rel = rms(outs[0], outs[1]) / U.rms(outs[0])
+    per_row = (outs[0] - outs[1]).pow(2).mean(dim=(1, 2)).sqrt() / outs[0].pow(2).mean(dim=(1, 2)).sqrt()
+    print(f"full-width layer, 12 x 640 rows: bf16 vs fp32 engine relative rms {rel:.3e}, worst row {float(per_row.max()):.3e}")
+    assert rel < 2e-2 and float(per_row.max()) < 3e-2, (rel, per_row)
 
 
 @pytest.mark.parametrize("dname,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
@@ -558,3 +675,196 @@ def test_blockwise_sampler_bf16_within_reference_noise(golden, tiny_models, case
         continuation_latent=g["tiny.blk_cont"] if cont else None, x_inits=xi, **SAMPLER_CASES[opts])
     e = rms(lat, g[f"tiny.f32.blockwise.{case}"])
     assert e < _bf16_budget(g, f"tiny.bf16.blockwise.{case}", f"tiny.f32.blockwise.{case}"), e
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY §8f rows
+def test_voice_cache_is_bit_identical_and_shared_voice_equals_replicated(golden, tiny_models):
+    """Per-voice cache (§8f-1; the reference re-encodes the voice per chunk: handler.py:750-758, model.py:615-621):
+    * a captured voice bound instead of get_kv_cache_speaker gives BIT-identical latents, repeatedly (the bound copy is private,
+      so the in-place speaker-KV scaling of one request cannot leak into the cached voice), on both engines;
+    * one voice with batch 1 shared by two text rows (stride-0 addressing) equals the same voice replicated per row."""
+    g = golden
+    ids, tm = g["tinyb2.ids"], g["tinyb2.tmask"].bool()
+    spk1, sm1 = g["tinyb2.spk"][:1], g["tinyb2.smask"][:1].bool()
+    x0 = g["tinyb2.x0"]
+    for name in ("f32", "bf16"):
+        m = tiny_models[name]
+        for case in ("cfg_default", "all_options"):
+            kw = SAMPLER_CASES[case]
+            def run(spk=spk1, sm=sm1, **extra):
+                return E.sample_euler_cfg_independent_guidances(m, spk, sm, ids, tm, rng_seed=0, sequence_length=32, x_init=x0, **kw, **extra)
+            fresh = run()
+            voice = m.capture_voice(m.get_kv_cache_speaker(spk1.to(m.dtype), sm1))
+            assert voice.nbytes > 0
+            a, b = run(speaker_kv=voice), run(speaker_kv=voice)
+            assert torch.equal(fresh, a) and torch.equal(a, b), (name, case)
+            rep = run(spk=spk1.expand(2, -1, -1).contiguous(), sm=sm1.expand(2, -1).contiguous())
+            assert torch.equal(fresh, rep), (name, case)
+            voice.close()
+    # a voice from another model is refused (different precision)
+    v = tiny_models["f32"].capture_voice(tiny_models["f32"].get_kv_cache_speaker(spk1, sm1))
+    with pytest.raises(RuntimeError, match="different model"):
+        tiny_models["bf16"].bind_voice(v)
+
+
+def test_handler_entry_points_with_voice_cache(golden, tiny_models):
+    """`handler(job)` / `_synthesize(job_input, job_id)` (reference handler.py:682-816): validation messages, seed fallback to the
+    top-level key, chunking switch, response shape; a registered `speaker_voice` is encoded once and served from the per-voice cache
+    afterwards with identical audio."""
+    from echo_tts_amd import handler as H
+    m = tiny_models["f32"]
+    dac = E.DAC(TINY_DAC, R.make_dac_weights(TINY_DAC, 0), device=DEV)
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    H.configure(m, dac, st, voices={"alice": (golden["tiny.spk"], golden["tiny.smask"].bool())})
+    assert H.handler({"id": "1", "input": {}}) == {"error": "Missing or invalid 'text' field (expected string)"}
+    assert H._synthesize({"text": 5}) == {"error": "Missing or invalid 'text' field (expected string)"}
+    assert H._synthesize({"text": "   "}) == {"error": "Text cannot be empty"}
+    assert H._synthesize({"text": "x" * 4001}) == {"error": "Text too long: 4001 characters (max 4000)"}
+    assert H._synthesize({"text": "Hi.", "speaker_voice": "bob"}) == {"error": "speaker_voice 'bob' not found"}
+    assert H._synthesize({"action": "health_check"})["status"] == "healthy"
+    text = "First sentence here. Second sentence follows, with a clause. Third one, which is a little longer than the others!"
+    p = {"num_steps": 4, "sequence_length": 32, "target_duration_seconds": 3.0}
+    job = {"id": "j", "input": {"text": text, "speaker_voice": "alice", "seed": 11, "parameters": p}}
+    r1 = H.handler(job)
+    assert r1.get("status") == "completed", r1
+    assert r1["metadata"]["seed"] == 11 and r1["metadata"]["sample_rate"] == 44100 and r1["metadata"]["chunks"] >= 2
+    assert abs(r1["metadata"]["duration"] - r1["audio"].shape[-1] / 44100) < 1e-9 and r1["audio"].dim() == 2
+    misses = H._State.cache.misses
+    r2 = H.handler(job)
+    assert H._State.cache.misses == misses and H._State.cache.hits >= 1
+    assert torch.equal(r1["audio"], r2["audio"])
+    # parameters.seed wins over the top-level seed; max_chars_per_chunk <= 0 and junk switch chunking off / fall back to 300
+    r3 = H._synthesize({"text": text, "seed": 11, "parameters": dict(p, seed=12, max_chars_per_chunk=0)})
+    assert r3["metadata"]["seed"] == 12 and r3["metadata"]["chunks"] == 1
+    r4 = H._synthesize({"text": text, "parameters": dict(p, max_chars_per_chunk="junk", num_steps=2)})
+    assert r4.get("status") == "completed" and r4["metadata"]["chunks"] == len(H.chunk_text_for_audio(text, 300, 3.0))
+    assert H._build_sample_fn({"sequence_length": None}).keywords["sequence_length"] is None      # the sampler reads None as 640
+    # the batched, cached, device-post-processed path equals the reference-shaped sequential path (one call per chunk, torch post-processing)
+    seq = H.synthesize({"text": text, "parameters": dict(p, seed=11, max_chunk_batch=1)}, m, dac, st,
+                       speaker_latent=golden["tiny.spk"], speaker_mask=golden["tiny.smask"].bool())
+    assert seq["audio"].shape == r1["audio"].shape and rms(seq["audio"], r1["audio"]) <= WAV_TOL
+
+
+def test_streaming_decode_equals_whole_utterance_decode():
+    """§8f-3: DACStream (causal chunked decode with carried left context) against the whole-utterance decode, tiny and
+    FULL-SIZE Fish S1-DAC: concatenated chunks == one-shot decode within 1e-6 RMS (and within 1e-4 of the signal RMS)."""
+    for cfg, T, blocks in ((TINY_DAC, 40, (8, 8, 4, 20)), (R.DacConfig(), 64, (16, 16, 16, 16))):
+        w = R.make_dac_weights(cfg, 0)
+        dac = E.DAC(cfg, w, device=DEV)
+        pca = R.make_pca(cfg, 80, 0)
+        st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+        lat = torch.randn((1, T, 80), generator=torch.Generator().manual_seed(2))
+        whole = E.ae_decode(dac, st, lat)
+        from echo_tts_amd.autoencoder import DACStream
+        stream = DACStream(dac, st)
+        assert 9 <= stream.context <= 16
+        parts, pos = [], 0
+        for n in blocks:
+            parts.append(stream.push(lat[:, pos:pos + n]))
+            assert parts[-1].shape == (1, 1, n * 2048)
+            pos += n
+        got = torch.cat(parts, dim=-1)
+        e = rms(got, whole)
+        print(f"streaming decode ({T} frames in {len(blocks)} chunks, context {stream.context}): rms {e:.3e} (signal {U.rms(whole):.3e})")
+        assert got.shape == whole.shape and e < 1e-6 and e < 1e-4 * U.rms(whole)
+        # a too-short context must be visible (the test can fail): context 0 differs right after every chunk boundary
+        bad = DACStream(dac, st, context=0)
+        bad.push(lat[:, :blocks[0]])
+        tail = bad.push(lat[:, blocks[0]:blocks[0] + blocks[1]])
+        assert rms(tail, whole[..., blocks[0] * 2048:(blocks[0] + blocks[1]) * 2048]) > 1e-5
+
+
+def test_blockwise_streaming_api(golden, tiny_models):
+    """sample_blockwise_stream yields every block as it is sampled and reproduces the reference-shaped blockwise sampler bit for
+    bit; stream_audio_blockwise turns the blocks into audio chunk by chunk, equal to decoding the final latent at once."""
+    from echo_tts_amd import inference_blockwise as IB
+    g, m = golden, tiny_models["f32"]
+    args = (g["tiny.spk"], g["tiny.smask"].bool(), g["tiny.ids"], g["tiny.tmask"].bool())
+    kw = dict(SAMPLER_CASES["cfg_default"])
+    blocks = [8, 8, 16]
+    whole = IB.sample_blockwise_euler_cfg_independent_guidances(m, *args, rng_seed=4, block_sizes=blocks, **kw)
+    seen, starts = [], []
+    for start, blk, prefix in IB.sample_blockwise_stream(m, *args, rng_seed=4, block_sizes=blocks, **kw):
+        starts.append(start)
+        seen.append(blk.clone())
+        assert prefix.shape[1] == start + blk.shape[1]
+    assert starts == [0, 8, 16] and torch.equal(torch.cat(seen, dim=1), whole)
+    dac = E.DAC(TINY_DAC, R.make_dac_weights(TINY_DAC, 0), device=DEV)
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    chunks = list(IB.stream_audio_blockwise(m, dac, st, *args, rng_seed=4, block_sizes=blocks, **kw))
+    assert [c.shape[-1] for c in chunks] == [b * 2048 for b in blocks]
+    assert rms(torch.cat(chunks, dim=-1), E.ae_decode(dac, st, whole)) < 1e-6
+
+
+def test_post_processing_kernels_against_reference_kats(golden):
+    """§8f-2: the HIP post-processing kernels (csrc/postproc.hip) against the known answers the reference produced
+    (tests/golden/host.safetensors: find_flattening_point on three latents, crossfade_chunks and normalize_chunk_boundaries on
+    three chunks) and against the torch form on edge cases (short chunks whose overlap is len // 4, silent / loud tails,
+    a window longer than the chunk, zero-length results)."""
+    from echo_tts_amd import handler as H
+    from echo_tts_amd import inference as inf
+    want = golden["__meta__"]["host"]["flattening"]
+    lats = torch.stack([golden[f"flat.{i}"] for i in range(3)]).to(DEV)
+    assert inf.find_flattening_points(lats) == want
+    assert [inf.find_flattening_point(lats[i]) for i in range(3)] == want
+    assert inf.find_flattening_points(torch.zeros((1, 30, 80), device=DEV)) == [0]
+    assert inf.find_flattening_points(torch.ones((1, 30, 80), device=DEV) * 3) == [30]
+    noisy = torch.randn((2, 640, 80), generator=torch.Generator().manual_seed(1))
+    noisy[1, 200:] = 0
+    assert inf.find_flattening_points(noisy.to(DEV)) == [inf.find_flattening_point(noisy[0]), inf.find_flattening_point(noisy[1])] == [640, 200]
+    a, b, c = (golden[k].to(DEV) for k in ("post.a", "post.b", "post.c"))
+    xf = H.crossfade_chunks_device([a, b, c], 4410)
+    assert xf.shape == golden["post.crossfade"].shape and float((xf.cpu() - golden["post.crossfade"]).abs().max()) < 1e-6
+    nb = H.normalize_chunk_boundaries_device([a, b, c], min_silence_samples=2000)
+    assert nb.shape == golden["post.normalize"].shape and float((nb.cpu() - golden["post.normalize"]).abs().max()) < 1e-6
+    gen = torch.Generator().manual_seed(3)
+    cases = []
+    for lens in ((50, 7, 3, 400), (4410 * 4, 100, 4410 * 8), (1, 1), (30000, 20000)):
+        chunks = [torch.randn((1, n), generator=gen) * 0.2 for n in lens]
+        chunks[0][..., -min(lens[0], 9):] = 0.001                   # a quiet tail shorter than the minimum silence
+        cases.append(chunks)
+    loud = [torch.ones((1, 5000)) * 0.5, torch.zeros((1, 3000)), torch.ones((1, 100)) * 0.5]     # no silence / all silence
+    cases.append(loud)
+    for chunks in cases:
+        dev = [x.to(DEV) for x in chunks]
+        for ms in (22050, 2000, 4):
+            ref = H.normalize_chunk_boundaries([x.clone() for x in chunks], min_silence_samples=ms)
+            got = H.normalize_chunk_boundaries_device(dev, min_silence_samples=ms)
+            assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) < 1e-6, ([x.shape[-1] for x in chunks], ms)
+        ref = H.crossfade_chunks([x.clone() for x in chunks], 4410)
+        got = H.crossfade_chunks_device(dev, 4410)
+        assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) < 1e-6
+        rows = [x.reshape(-1) for x in dev]
+        assert H.trailing_quiet_device(rows, 2 * 2000, 0.01) == [H._trailing_quiet(x, min(x.shape[-1], 4000), 0.01) for x in chunks]
+
+
+def test_checkpoint_loaders_round_trip(tmp_path, golden):
+    """§8f-4: load_model_from_path / load_fish_ae_from_path / load_pca_state_from_path read safetensors files with the reference's
+    key layout (inference.py:14-113 read the same files from the Hugging Face cache) and give the same outputs as the in-memory
+    constructors; workspace sizing (SURVEY §8b `echo_workspace_bytes`) grows the caches up front."""
+    import safetensors.torch as sft
+    from echo_tts_amd import inference as inf
+    w = R.make_dit_weights(TINY, seed=0)
+    sft.save_file({k: v.contiguous() for k, v in w.items()}, str(tmp_path / "dit.safetensors"))
+    dw = R.make_dac_weights(TINY_DAC, 0)
+    sft.save_file({k: v.contiguous() for k, v in dw.items()}, str(tmp_path / "dac.safetensors"))
+    pca = R.make_pca(TINY_DAC, 80, 0)
+    sft.save_file({"pca_components": pca.pca_components.contiguous(), "pca_mean": pca.pca_mean.contiguous(),
+                   "latent_scale": torch.tensor(pca.latent_scale)}, str(tmp_path / "pca.safetensors"))
+    m = inf.load_model_from_path(str(tmp_path / "dit.safetensors"), dtype=torch.float32, config=TINY)
+    dac = inf.load_fish_ae_from_path(str(tmp_path / "dac.safetensors"), config=TINY_DAC)
+    st = inf.load_pca_state_from_path(str(tmp_path / "pca.safetensors"))
+    g = golden
+    args = (g["tiny.spk"], g["tiny.smask"].bool(), g["tiny.ids"], g["tiny.tmask"].bool())
+    before = m.workspace_bytes()
+    m.reserve_workspace(1, 32, g["tiny.ids"].shape[1], g["tiny.spk"].shape[1])
+    grown = m.workspace_bytes()
+    assert grown > before
+    lat = E.sample_euler_cfg_independent_guidances(m, *args, rng_seed=0, sequence_length=32, x_init=g["tiny.x0"], **SAMPLER_CASES["cfg_default"])
+    assert rms(lat, g["tiny.f32.euler.cfg_default"]) < LAT_TOL
+    wav = E.ae_decode(dac, st, lat)
+    assert rms(wav, R.ae_decode(dw, TINY_DAC, pca, lat.cpu())) < WAV_TOL
+    m2 = inf.load_model_from_path(str(tmp_path / "dit.safetensors"), dtype=torch.float32, config=TINY, delete_blockwise_modules=True)
+    assert not m2.has_latent_encoder and m.has_latent_encoder
