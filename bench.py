@@ -328,7 +328,8 @@ def main() -> None:
         try:
             eager = eager_gpu_baseline(state, pca, ids, tmask, spk, smask, sampler_kw, device)
         except Exception as ex:      # a baseline must never take the bench line down
-            eager = {"error": f"{type(ex).__name__}: {ex}"}
+            import traceback
+            eager = {"error": f"{type(ex).__name__}: {ex}", "where": traceback.format_exc().strip().splitlines()[-3:]}
     state = None
 
     if rank == 0:

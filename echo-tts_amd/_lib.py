@@ -85,7 +85,7 @@ class EchoAttnDesc(C.Structure):
                 ("O", vp), ("o_ld", c_i64), ("o_row_stride", c_i64),
                 ("G", vp), ("g_ld", c_i64), ("g_row_stride", c_i64),
                 ("S", C.c_int), ("H", C.c_int), ("rows", C.c_int), ("nseg", C.c_int),
-                ("seg", EchoAttnSeg * 4), ("causal", C.c_int), ("scale", C.c_float), ("prof", vp)]
+                ("seg", EchoAttnSeg * 4), ("causal", C.c_int), ("scale", C.c_float), ("prof", vp), ("redo", vp)]
 
 
 class EchoProfile(C.Structure):

@@ -10,6 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libechohip.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "dac.hip", "postproc.hip", "engine.hip"]
+# attention.hip: the one-wave-per-SIMD kernel places every VALU instruction in an MFMA gap by hand; SLP vectorisation would turn its
+# scalar fp32 adds into v_pk_add_f32 plus the v_mov shuffles that feed them (cdna_hip_programming.md Appendix B, pitfalls)
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -35,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     for src, p in procs:

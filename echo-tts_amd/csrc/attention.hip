@@ -20,6 +20,7 @@
 // of 8 consecutive keys = exactly the B-operand fragments of the following Oᵀ += Vᵀ·Pᵀ MFMAs, so
 // P never leaves registers (cdna_hip_programming.md §3 "accumulator tile as the next operand").
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -73,6 +74,8 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   unsigned long long k_t0 = 0, k_r0 = 0, pa = 0, pb = 0;
   if (PROF) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
+  // second pass behind attn4_kernel: only the 256-query blocks it flagged are done again here (with per-tile rescaling)
+  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * ((gridDim.x + 1) >> 1) + (blockIdx.x >> 1)] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wid & 3, kh = wid >> 2;
@@ -427,6 +430,401 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// attn4_kernel: the joint attention of the EchoDiT steps (no causal mask, no per-key bias) as 4 waves x 64 queries, ONE wave
+// per SIMD on the 512-entry register file (cdna_hip_programming.md Appendix B "4-wave, one-wave-per-SIMD"; round-1 DESIGN §3.2:
+// attn_kernel's two waves per SIMD overlap their MFMA / VALU / LDS streams only partly and end with an LDS merge).
+//
+// One workgroup = 256 queries of one (row, head); wave w owns queries 64 w .. 64 w + 63 as two INDEPENDENT 32-query streams
+// q = 0, 1 that run half a tile apart inside one instruction stream: while the matrix pipe works on one stream's 16 MFMAs, the
+// vector ALU runs the other stream's softmax in the MFMA gaps.  MFMA order per 64-key tile t:
+//     S0(t) = K(t) Q0^T     PV1(t-1)     S1(t) = K(t) Q1^T     PV0(t)           (16 x v_mfma_f32_32x32x16_bf16 each)
+// softmax of stream 0 / tile t occupies the 32 gaps of PV1(t-1) and S1(t), softmax of stream 1 those of PV0(t) and S0(t+1): every
+// softmax is complete before the PV phase that consumes its P.  Live score registers: 2 x 32.  Fragments come from LDS one per
+// MFMA, two MFMAs ahead.  Same LDS images, LDS-DMA, segment streams, key permutation and in-register P as attn_kernel; rings of
+// three K and three V^T tiles (K two tiles ahead, V one), one workgroup barrier per tile, the loop unrolled by three so that ring
+// slots are immediates.
+//
+// The tile loop contains NO branch that modifies score or output registers: hipcc answers such a branch (a conditional rescale of
+// O, a conditional masking of S) with v_accvgpr round trips of the accumulators on the hot path - measured 2x SLOWER than
+// attn_kernel.  Instead:
+//  * masking is an MFMA operand: every score chain starts from cz[kb] = 0 for valid keys, -inf for the keys past a segment's end
+//    (S = K Q^T + cz), recomputed branch-free every step in place of the zero the chains would need anyway;
+//  * the reference point m of a stream is FIXED at its first tile's row maximum and every tile is exponentiated against it: exact
+//    as long as no later score exceeds it by more than 2^FAST_LOG2_RANGE in the log2 domain (P <= 2^40: bf16 has fp32's exponent
+//    range, l and O accumulate in fp32) - RMS-normalised q, k stay far inside.  A workgroup that sees a score beyond the range
+//    reports it in `redo`, and launch_attention_bf16 runs attn_kernel (per-tile rescaling) right behind for exactly those
+//    workgroups: always correct, fast whenever the scores behave.
+constexpr float FAST_LOG2_RANGE = 40.0f;
+constexpr int SMEM4 = 3 * (K_TILE_BYTES + V_TILE_BYTES) + 16;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+__device__ __forceinline__ float half_max(float v) {      // max over lanes l and l ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// LDS fragment read hidden from hipcc's wait-count bookkeeping (cdna_hip_programming.md §5.7 item 1, form iii): hipcc waits
+// lgkmcnt(0) in front of every third MFMA of a rolling three-fragment window - i.e. also for the read it has just issued - which
+// exposes a full LDS round trip 21 times per tile (measured: 2.7 us per tile instead of ~1.2).  Here every MFMA gap issues exactly
+// one read and lds_wait<2>() in front of MFMA g retires exactly fragment g (reads return in order; the loop has no other LGKM user).
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr, int off) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(off));
+  return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);          // no MFMA may be hoisted above the wait (guide rule 18)
+}
+
+struct Soft {            // one query stream of a wave
+  f32x16 s[2];           // raw scores of the current tile, [kb]: register r = key 32 kb + 16 (r >> 3) + 8 fh + (r & 7); P after the exponentials
+  bf16x8 pf[4];          // P^T as the B operand of the four PV k-steps
+  float m, l, mc;        // reference point of the raw scores, running denominator, m * c
+  float mxp[4], rs[4];
+};
+
+// DIAG bits (timing experiments only, wrong results): 1 = no softmax VALU work, 2 = no MFMAs, 4 = no LDS-DMA in the loop, 8 = no barrier / vmcnt wait per tile
+template <int DIAG>
+__global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [3][16 KiB] | V ring [3][16 KiB] | 4 range flags
+  constexpr int QW = 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.z, head = blockIdx.y;
+  const int qbase = blockIdx.x * QW;
+  const int fr = lane & 31, fh = lane >> 5;
+  const bool wave_on = qbase + wid * 64 < p.S;          // wave-uniform: a wave without queries only stages tiles
+  char* const kring = smem;
+  char* const vring = smem + 3 * K_TILE_BYTES;
+  int* const wflags = (int*)(smem + 3 * (K_TILE_BYTES + V_TILE_BYTES));
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][16 kk + 8 fh + 0..7] for both streams
+  bf16x8 qf[2][8];
+  int qi[2]; bool q_ok[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qi[qb] = qbase + wid * 64 + qb * 32 + fr;
+    q_ok[qb] = qi[qb] < p.S;
+    const int qc = q_ok[qb] ? qi[qb] : p.S - 1;
+    const bf16_t* qp = p.Q + (long)row * p.q_row_stride + (long)qc * p.q_ld + head * HD + 8 * fh;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + 16 * kk);
+  }
+
+  // ---- per-segment key counts and operands, resolved once into scalar registers (see attn_kernel)
+  int nkraw[4];
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) nkraw[sgi] = (sgi < p.nseg ? p.seg[sgi].nkeys : p.seg[0].nkeys)[row];
+  auto seg_keys = [&](int sgi) -> int { const int nk = sgi < p.nseg ? nkraw[sgi] : 0; return nk < 0 ? 0 : nk; };
+  const int nk0 = seg_keys(0), nk1 = seg_keys(1), nk2 = seg_keys(2), nk3 = seg_keys(3);
+  auto NK = [&](int s) -> int { return s == 0 ? nk0 : s == 1 ? nk1 : s == 2 ? nk2 : s == 3 ? nk3 : 0; };
+  auto NT = [&](int s) -> int { return (NK(s) + KT - 1) / KT; };
+  const int total_tiles = NT(0) + NT(1) + NT(2) + NT(3);
+  const char* kb_[4]; const char* vb_[4]; long kld_[4], vld_[4];
+  int mod0 = 0;
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi)
+    if (sgi < p.nseg && mod0 == 0 && p.seg[sgi].kv_mod > 0) mod0 = p.seg[sgi].kv_mod;
+  const int rmod0 = mod0 > 0 ? row % mod0 : row;
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) {
+    kb_[sgi] = nullptr; vb_[sgi] = nullptr; kld_[sgi] = 0; vld_[sgi] = 0;
+    if (sgi < p.nseg) {
+      const AttnSeg& sg = p.seg[sgi];
+      const int kvrow = sg.kv_mod == 0 ? row : (sg.kv_mod == mod0 ? rmod0 : row % sg.kv_mod);
+      kb_[sgi] = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
+      vb_[sgi] = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
+      kld_[sgi] = sg.k_ld * 2; vld_[sgi] = sg.vt_ld * 2;
+    }
+  }
+  auto next_seg = [&](int sg) -> int { ++sg; while (sg < 4 && NK(sg) == 0) ++sg; return sg; };
+
+  // DMA roles: a tile is 16 K pieces (4 keys x 256 B) + 16 V pieces (8 d-rows x 128 B); wave w issues pieces 4 w .. 4 w + 3 of each
+  int k_r[4], k_c[4], v_d[4], v_c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k_r[i] = (wid * 4 + i) * 4 + (lane >> 4);
+    k_c[i] = ((lane & 15) ^ (k_r[i] & 15)) << 4;
+    v_d[i] = (wid * 4 + i) * 8 + (lane >> 3);
+    v_c[i] = ((lane & 7) ^ ((v_d[i] >> 1) & 7)) << 4;
+  }
+  Stream ks, vs, cur;
+  unsigned k_off[4], v_off[4];
+  auto k_offsets = [&]() {
+    const int kld = (int)SEL4(kld_, ks.seg), last = ks.nk - 1 - ks.k0;      // rows past the segment's last key repeat it (masked by cz)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k_off[i] = (unsigned)(min(k_r[i], last) * kld + k_c[i]);
+  };
+  auto k_enter = [&](int sg) {
+    ks.seg = sg; ks.k0 = 0; ks.nk = NK(sg); ks.ptr = SEL4(kb_, sg); ks.step = (int)SEL4(kld_, sg) * KT;
+    k_offsets();
+  };
+  auto k_advance = [&]() {                       // past the end the stream stays on the last tile
+    if (ks.k0 + KT < ks.nk) {
+      ks.k0 += KT; ks.ptr += ks.step;
+      if (ks.k0 + KT > ks.nk) k_offsets();
+    } else {
+      const int sg = next_seg(ks.seg);
+      if (sg < 4) k_enter(sg);
+    }
+  };
+  auto v_enter = [&](int sg) {
+    vs.seg = sg; vs.k0 = 0; vs.nk = NK(sg); vs.ptr = SEL4(vb_, sg); vs.step = KT * 2;
+    const int vld = (int)SEL4(vld_, sg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_off[i] = (unsigned)(v_d[i] * vld + v_c[i]);
+  };
+  auto v_advance = [&]() {
+    if (vs.k0 + KT < vs.nk) { vs.k0 += KT; vs.ptr += vs.step; }
+    else { const int sg = next_seg(vs.seg); if (sg < 4) v_enter(sg); }
+  };
+  auto c_enter = [&](int sg) { cur.seg = sg; cur.k0 = 0; cur.nk = NK(sg); };
+  auto c_advance = [&]() {
+    if (cur.k0 + KT < cur.nk) cur.k0 += KT;
+    else { const int sg = next_seg(cur.seg); if (sg < 4) c_enter(sg); }
+  };
+  auto dma_k = [&](int i, char* kdst) __attribute__((always_inline)) { glds16(ks.ptr + k_off[i], kdst + i * 1024); };
+  auto dma_v = [&](int i, char* vdst) __attribute__((always_inline)) { glds16(vs.ptr + v_off[i], vdst + i * 1024); };
+
+  const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped (see attn_kernel)
+  const int sw_v = (lane >> 1) & 7;
+  const int sw_k = pi_row & 15;
+  // fragment read addresses (bytes from the start of a tile image), + kb * 8192 / + db * 4096 as immediates
+  // (the ring base is part of the per-lane pointer, so that slot, kb and db offsets fold into the ds_read's offset field)
+  unsigned ka[8], va[4];
+  {
+    const unsigned kbase = (unsigned)(unsigned long)(lptr_t)kring, vbase = (unsigned)(unsigned long)(lptr_t)vring;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ka[kk] = kbase + pi_row * 256 + (((2 * kk + fh) ^ sw_k) << 4);
+#pragma unroll
+    for (int kss = 0; kss < 4; ++kss) va[kss] = vbase + fr * 128 + (((2 * kss + fh) ^ sw_v) << 4);
+  }
+  const float c = p.scale * 1.4426950408889634f;
+  f32x16 o[2][4];
+  Soft st[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
+    st[qb].m = -1e30f; st[qb].l = 0.0f; st[qb].mc = -1e30f * c;
+    // "tile -1" (makes the first step uniform): P = 0 everywhere.  The elements the skipped slots 6-15 would have exponentiated
+    // (e < 20: kb 0, and registers 0-3 of kb 1) are already 0, the others are raw -inf and become 0 in slots 16-21
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[qb].s[0][r] = 0.0f; st[qb].s[1][r] = r < 4 ? 0.0f : -INFINITY; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st[qb].pf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; st[qb].mxp[i] = 0.f; st[qb].rs[i] = 0.f; }
+  }
+  int ovf = 0;             // a score left the fixed reference's range (wave-uniform)
+  f32x16 cz[2];            // start value of the score chains of the current tile: 0 / -inf per key (see header)
+
+  // ---- softmax of stream q, cut into 32 slots that ride in the MFMA gaps of the other stream
+  auto soft_slot = [&](auto qc_, auto ic_) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc_)::value, I = decltype(ic_)::value;
+    Soft& S = st[q];
+    if constexpr (I < 4) {
+      constexpr int kb = I >> 1, h = 8 * (I & 1);
+      const float a = fmaxf(fmaxf(S.s[kb][h], S.s[kb][h + 1]), S.s[kb][h + 2]);
+      const float b = fmaxf(fmaxf(S.s[kb][h + 3], S.s[kb][h + 4]), S.s[kb][h + 5]);
+      S.mxp[I] = fmaxf(fmaxf(a, b), fmaxf(S.s[kb][h + 6], S.s[kb][h + 7]));
+    } else if constexpr (I == 4) {
+      S.mxp[0] = half_max(fmaxf(fmaxf(S.mxp[0], S.mxp[1]), fmaxf(S.mxp[2], S.mxp[3])));
+    } else if constexpr (I == 5) {
+      const float mx = S.mxp[0];
+      S.m = S.m == -1e30f ? mx : S.m;                        // the first tile sets the reference; O and l are still 0
+      if (__any((mx - S.m) * c > FAST_LOG2_RANGE)) ovf = 1;  // only a scalar is written in here
+      S.mc = S.m * c;
+    } else if constexpr (I < 22) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        constexpr int e0 = 2 * (I - 6);
+        const int e = e0 + u;
+        const int kss = e >> 3, kb = kss >> 1, r = 8 * (kss & 1) + (e & 7);
+        S.s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S.s[kb][r], c, -S.mc));
+      }
+      if constexpr (((2 * (I - 6) + 1) & 7) == 7) {         // the 8 values of PV k-step kss are exponentiated: pack them
+        constexpr int kss = (2 * (I - 6)) >> 3;
+        S.pf[kss] = pack8(S.s[kss >> 1], 8 * (kss & 1));
+      }
+    } else if constexpr (I < 30) {
+      constexpr int g = I - 22;                             // elements 4 g .. 4 g + 3
+      constexpr int kss = g >> 1, kb = kss >> 1, r0 = 8 * (kss & 1) + 4 * (g & 1);
+      const float t = (S.s[kb][r0] + S.s[kb][r0 + 1]) + (S.s[kb][r0 + 2] + S.s[kb][r0 + 3]);
+      if constexpr (g < 4) S.rs[g] = t; else S.rs[g - 4] += t;
+    } else if constexpr (I == 30) {
+      S.rs[0] = half_sum((S.rs[0] + S.rs[1]) + (S.rs[2] + S.rs[3]));
+    } else {
+      S.l += S.rs[0];
+    }
+  };
+
+  // ---- MFMA phases.  VQ: the stream whose softmax rides in the gaps (-1 = none), slots SL0 .. SL0 + 15.  Every MFMA takes its
+  // LDS fragment from the rolling window fq (two MFMAs ahead); the last two gaps of a phase already read the first two fragments of
+  // the NEXT phase (nxt0 / nxt1: their LDS byte addresses), so no phase starts with an exposed LDS round trip.
+  // FW fragments deep: with 3 in flight per wave (12 KiB per CU) the kernel ran at the LDS LATENCY, 1.36 us per tile for the reads alone
+  constexpr int FW = 8;
+  bf16x8 fq[FW];
+  // fragment j of a phase: kind 0 = K of S_q (kb = j >> 3, kk = j & 7), kind 1 = V^T of PV_q (kss = j >> 2, db = j & 3); slot = ring slot (a literal)
+  auto frag = [&](auto kindc, const int slot, auto jc) __attribute__((always_inline)) -> bf16x8 {
+    constexpr int kind = decltype(kindc)::value, j = decltype(jc)::value;
+    if constexpr (kind == 0) return lds_read16(ka[j & 7], slot * K_TILE_BYTES + (j >> 3) * 8192);
+    else return lds_read16(va[j >> 2], slot * V_TILE_BYTES + (j & 3) * 4096);
+  };
+  // one phase of 16 MFMAs.  KIND 0: S_q(t) = K(t) Q_q^T + cz (kb, kk); KIND 1: PV_q: O_q^T += V^T(tile) P_q^T (kss, db).  slot: its ring slot;
+  // nslot: the ring slot of the NEXT phase (which is of the other kind), whose first FW - 1 fragments the last gaps already read.
+  // DMA (S phases): this wave's 4 K + 4 V pieces at g = 0, 2, .. 14.
+  auto phase = [&](auto kindc, auto qc_, const int slot, const int nslot, auto vq_, auto sl0_, auto dmac_, char* kdst, char* vdst) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kindc)::value, q = decltype(qc_)::value, VQ = decltype(vq_)::value, SL0 = decltype(sl0_)::value;
+    constexpr bool DMA = decltype(dmac_)::value != 0;
+    sfor<0, 16>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value, j = g + FW - 1;
+      if constexpr (j < 16) fq[j % FW] = frag(kindc, slot, std::integral_constant<int, (j < 16 ? j : 0)>{});
+      else fq[j % FW] = frag(std::integral_constant<int, 1 - KIND>{}, nslot, std::integral_constant<int, (j >= 16 ? j - 16 : 0)>{});
+      lds_wait<FW - 1>();
+      if constexpr (DIAG & 2) asm volatile("" :: "v"(fq[g % FW]));
+      else if constexpr (KIND == 0) {
+        constexpr int kb = g >> 3, kk = g & 7;
+        if constexpr (kk == 0) st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], cz[kb], 0, 0, 0);
+        else st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], st[q].s[kb], 0, 0, 0);
+      } else {
+        constexpr int kss = g >> 2, db = g & 3;
+        o[q][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], st[q].pf[kss], o[q][db], 0, 0, 0);
+      }
+      if constexpr (VQ >= 0 && !(DIAG & 1)) soft_slot(std::integral_constant<int, (VQ < 0 ? 0 : VQ)>{}, std::integral_constant<int, SL0 + g>{});
+      if constexpr (DMA && (g & 1) == 0 && !(DIAG & 4)) { if constexpr (g < 8) dma_k(g >> 1, kdst); else dma_v((g - 8) >> 1, vdst); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 16> I16;
+  typedef std::integral_constant<int, -1> IN;
+
+  if (total_tiles > 0) {
+    {
+      int s0 = 0;
+      while (s0 < 3 && NK(s0) == 0) ++s0;
+      k_enter(s0); v_enter(s0); c_enter(s0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i, kring + wid * 4096);                          // K(0) -> K slot 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v(i, vring + wid * 4096);                          // V(0) -> V slot 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v(i, vring + 2 * V_TILE_BYTES + wid * 4096);       // and -> V slot 2: finite operands for PV1(-1), whose P is 0
+    k_advance();
+    if (total_tiles > 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_k(i, kring + K_TILE_BYTES + wid * 4096);         // K(1) -> K slot 1
+    }
+    k_advance();                      // ks -> tile 2, vs -> tile 1, cur = tile 0
+    v_advance();
+    // step t (slot sl = t % 3, a literal): reads K(t) [K slot sl], V(t-1) [V slot sl + 2], V(t) [V slot sl]; stages K(t+2) -> K slot
+    // sl + 2 and V(t+1) -> V slot sl + 1.  The fragment window enters phase j of step sl at offset (4 sl + j) % 3 = (sl + j) % 3.
+    auto step = [&](const int sl) __attribute__((always_inline)) {
+      if constexpr (!(DIAG & 8)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of K(t+1) / V(t) have landed ...
+        __syncthreads();                                    // ... and everyone's; every wave finished step t - 1
+      }
+      const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl == 0 ? 2 : sl - 1;
+      char* kdst = kring + sl2 * K_TILE_BYTES + wid * 4096;
+      char* vdst = vring + sl1 * V_TILE_BYTES + wid * 4096;
+      if (wave_on) {
+        // cz = 0 for key < vk (valid keys of tile t; >= 64: all), hugely negative otherwise: min(0, (vk - key - 0.5) * 1e30) with the
+        // lane part of the key index folded into x - two VALU operations per element, no VCC round trip
+        const float x = (float)(cur.nk - cur.k0 - 8 * fh);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cz[kb][r] = fminf(0.0f, __builtin_fmaf(x, 1e30f, -((float)(32 * kb + 16 * (r >> 3) + (r & 7)) + 0.5f) * 1e30f));
+        phase(I0{}, I0{}, sl, sl2, I1{}, I16{}, I1{}, kdst, vdst);     // S0(t)    | softmax 1 (t-1), slots 16-31   (next: PV1(t-1) from V slot sl2)
+        phase(I1{}, I1{}, sl2, sl, I0{}, I0{}, I0{}, kdst, vdst);      // PV1(t-1) | softmax 0 (t),   slots 0-15    (next: S1(t)    from K slot sl)
+        phase(I0{}, I1{}, sl, sl, I0{}, I16{}, I0{}, kdst, vdst);      // S1(t)    | softmax 0 (t),   slots 16-31   (next: PV0(t)   from V slot sl)
+        phase(I1{}, I0{}, sl, sl1, I1{}, I0{}, I0{}, kdst, vdst);      // PV0(t)   | softmax 1 (t),   slots 0-15    (next: S0(t+1)  from K slot sl1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the next step's S0: back in hipcc's books
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_k(i, kdst);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_v(i, vdst);
+      }
+      k_advance(); v_advance(); c_advance();
+    };
+    // the first two fragments of S0(0): K(0) has to be visible to every wave first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    sfor<0, FW - 1>([&](auto jc) __attribute__((always_inline)) { fq[decltype(jc)::value] = frag(I0{}, 0, jc); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < total_tiles; t += 3) { step(0); step(1); step(2); }
+    const int rem = total_tiles - t;
+    if (rem >= 1) step(0);
+    if (rem >= 2) step(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup ends
+    // ---- drain: softmax 1 (T-1) slots 16-31, then PV1(T-1) from V slot (T-1) % 3
+    if (wave_on) {
+      sfor<16, 32>([&](auto ic) __attribute__((always_inline)) { soft_slot(I1{}, ic); });
+      const int last = (total_tiles - 1) % 3;
+      auto drain = [&](const int vsl) __attribute__((always_inline)) {
+        sfor<0, FW - 1>([&](auto jc) __attribute__((always_inline)) { fq[decltype(jc)::value] = frag(I1{}, vsl, jc); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase(I1{}, I1{}, vsl, 0, IN{}, I0{}, I0{}, kring, vring);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      if (last == 0) drain(0); else if (last == 1) drain(1); else drain(2);
+    }
+  }
+  // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
+  if (lane == 0) wflags[wid] = ovf;
+  __syncthreads();
+  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
+  if (!wave_on) return;
+
+  // ---- epilogue: lane holds O[q = 32 qb + fr][32 d + 8 g + 4 fh + 0..3]; gate values requested as one batch per query stream
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (!q_ok[qb]) continue;
+    const int q = qi[qb];
+    uint2 gq[4][4];
+    const bf16_t* gp = p.G ? p.G + (long)row * p.g_row_stride + (long)q * p.g_ld + head * HD + 4 * fh : nullptr;
+    if (gp) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[d][g] = *(const uint2*)(gp + 32 * d + 8 * g);
+    }
+    const float inv_l = 1.0f / st[qb].l;
+    bf16_t* op = p.O + (long)row * p.o_row_stride + (long)q * p.o_ld + head * HD + 4 * fh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[qb][d][4 * g + i] * inv_l));
+        if (gp) {
+          float gv[4];
+          Vec4<bf16_t>::unpack(gq[d][g], gv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
+        }
+        *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
+      }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
@@ -443,6 +841,35 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.S + QT - 1) / QT, a.H, a.rows);
   bool bias = false;
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
+  // ECHO_ATTN4=1 selects attn4_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention.  Measured (round 2, DESIGN.md
+  // §3.2): it ties attn_kernel at the bench shape (620 vs 627 TFLOP/s at 24 rows) and loses below 8 rows, so attn_kernel stays the default.
+  static const bool use4 = getenv("ECHO_ATTN4") && atoi(getenv("ECHO_ATTN4")) != 0;
+  if (!a.causal && !bias && !a.prof && use4 && a.redo) {
+    // the joint attention of the sampler steps (and the text encoder): 4 waves x 64 queries, one wave per SIMD, then attn_kernel
+    // for the (normally zero) workgroups whose scores left the fast kernel's range; both on the caller's stream
+    static std::atomic<unsigned long long> prep4[8];
+    static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
+    const int di = diag == 1 ? 1 : diag == 2 ? 2 : diag == 3 ? 3 : diag == 7 ? 4 : diag == 11 ? 5 : diag == 15 ? 6 : diag == 4 ? 7 : 0;
+    const void* k4[8] = {(const void*)attn4_kernel<0>, (const void*)attn4_kernel<1>, (const void*)attn4_kernel<2>, (const void*)attn4_kernel<3>,
+                         (const void*)attn4_kernel<7>, (const void*)attn4_kernel<11>, (const void*)attn4_kernel<15>, (const void*)attn4_kernel<4>};
+    if (hipError_t e = ensure_dyn_lds(k4[di], SMEM4, prep4[di]); e != hipSuccess) return e;
+    const dim3 g4((a.S + 255) / 256, a.H, a.rows);
+    switch (di) {
+      case 1: hipLaunchKernelGGL(attn4_kernel<1>, g4, dim3(256), SMEM4, st, a); break;
+      case 2: hipLaunchKernelGGL(attn4_kernel<2>, g4, dim3(256), SMEM4, st, a); break;
+      case 3: hipLaunchKernelGGL(attn4_kernel<3>, g4, dim3(256), SMEM4, st, a); break;
+      case 4: hipLaunchKernelGGL(attn4_kernel<7>, g4, dim3(256), SMEM4, st, a); break;
+      case 5: hipLaunchKernelGGL(attn4_kernel<11>, g4, dim3(256), SMEM4, st, a); break;
+      case 6: hipLaunchKernelGGL(attn4_kernel<15>, g4, dim3(256), SMEM4, st, a); break;
+      case 7: hipLaunchKernelGGL(attn4_kernel<4>, g4, dim3(256), SMEM4, st, a); break;
+      default: hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    AttnArgs b = a;
+    b.redo_filter = a.redo;
+    hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(512), SMEM, st, b);
+    return hipGetLastError();
+  }
   if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(512), SMEM, st, a);   // s_memtime stamps
   else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(512), SMEM, st, a);
   else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(512), SMEM, st, a);

@@ -156,7 +156,12 @@ struct AttnArgs {
   int causal;                   // only with nseg == 1 (encoder self-attention)
   float scale;
   void* prof;                   // diagnostic: per-wave {barrier, issue, compute, tiles} cycle sums (s_memtime); nullptr in production
+  // attn4_kernel (the fast joint-attention kernel) writes one word per 256-query workgroup into `redo` [rows][H][ceil(S / 256)]:
+  // non-zero = a score left its fixed-reference range and attn_kernel must redo that block; nullptr = attn_kernel only.
+  int* redo;
+  const int* redo_filter;       // set by the launcher on attn_kernel's second pass
 };
+inline long attn_redo_words(int rows, int H, int S) { return (long)rows * H * ((S + 255) / 256); }
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)

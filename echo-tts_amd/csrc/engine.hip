@@ -234,13 +234,13 @@ struct Engine : EngineBase {
 
   // ------------------------------------------------------------------ caches and workspaces
   DevBuf b_kv_text, b_vt_text, b_kv_spk, b_vt_spk, b_kv_lat, b_vt_lat, b_nkeys, b_bias_text, b_bias_spk;
-  DevBuf b_xin, b_x, b_xn, b_qkvg, b_vt_self, b_attn, b_h, b_vout, b_scores, b_biasrows, b_segmeta;
+  DevBuf b_xin, b_x, b_xn, b_qkvg, b_vt_self, b_attn, b_h, b_vout, b_scores, b_biasrows, b_segmeta, b_attn_redo;
   DevBuf b_mod, b_c1, b_c2, b_cond, b_sc, b_dn, b_xstate, b_vf32;
   DevBuf b_ex, b_exn, b_eqkvg, b_evt, b_eattn, b_eh, b_ein, b_enk;
   DevBuf b_dacA, b_dacB, b_dacC, b_dq, b_dscore, b_dvt, b_dmisc;
   std::vector<DevBuf*> all_bufs() {
     return {&b_kv_text, &b_vt_text, &b_kv_spk, &b_vt_spk, &b_kv_lat, &b_vt_lat, &b_nkeys, &b_bias_text, &b_bias_spk,
-            &b_xin, &b_x, &b_xn, &b_qkvg, &b_vt_self, &b_attn, &b_h, &b_vout, &b_scores, &b_biasrows, &b_segmeta,
+            &b_xin, &b_x, &b_xn, &b_qkvg, &b_vt_self, &b_attn, &b_h, &b_vout, &b_scores, &b_biasrows, &b_segmeta, &b_attn_redo,
             &b_mod, &b_c1, &b_c2, &b_cond, &b_sc, &b_dn, &b_xstate, &b_vf32,
             &b_ex, &b_exn, &b_eqkvg, &b_evt, &b_eattn, &b_eh, &b_ein, &b_enk,
             &b_dacA, &b_dacB, &b_dacC, &b_dq, &b_dscore, &b_dvt, &b_dmisc};
@@ -622,6 +622,8 @@ struct Engine : EngineBase {
       }
       a.nseg = n;
       if (n == 0) return fail("attention without keys");
+      CK(b_attn_redo.reserve((size_t)attn_redo_words(rows, H, S) * sizeof(int)));
+      a.redo = b_attn_redo.as<int>();
       if (profiling) {
         if (attn_events_used == attn_events.size()) {
           hipEvent_t e0, e1;
@@ -2033,6 +2035,16 @@ int echo_op_attention_bf16(const echo_attn_desc* d, void* stream) {
     a.seg[s].vt_head_stride = d->seg[s].vt_head_stride;
     a.seg[s].nkeys = d->seg[s].nkeys; a.seg[s].bias = d->seg[s].bias; a.seg[s].bias_row_stride = d->seg[s].bias_row_stride;
     a.seg[s].kv_mod = d->seg[s].kv_mod;
+  }
+  // range-report words of the fast joint-attention kernel (common.h AttnArgs::redo): the caller may pass its own buffer
+  // (needed when several streams run attention at once); otherwise one buffer per host thread and device
+  a.redo = (int*)d->redo;
+  if (!a.redo && a.rows > 0 && a.H > 0 && a.S > 0) {
+    static thread_local DevBuf redo_buf[64];
+    int dev = 0; (void)hipGetDevice(&dev);
+    DevBuf& rb = redo_buf[dev & 63];
+    if (hipError_t e = rb.reserve((size_t)attn_redo_words(a.rows, a.H, a.S) * sizeof(int)); e != hipSuccess) return op_status(e);
+    a.redo = rb.as<int>();
   }
   return op_status(launch_attention_bf16(a, (hipStream_t)stream));
 }

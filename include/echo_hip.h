@@ -204,6 +204,8 @@ typedef struct {
   const void* G; int64_t g_ld, g_row_stride;
   int S, H, rows, nseg; echo_attn_seg seg[4]; int causal; float scale;
   void* prof;                    /* diagnostic build only: (workgroups*4, 4) uint64 cycle sums; NULL normally */
+  void* redo;                    /* optional device scratch of rows * H * ceil(S / 256) int32 for the fast kernel's range report (DESIGN.md
+                                    3.2); NULL: the library uses a buffer of its own per host thread and device */
 } echo_attn_desc;
 int echo_op_attention_bf16(const echo_attn_desc* d, void* stream);
 

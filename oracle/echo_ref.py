@@ -533,6 +533,7 @@ def window_transformer(w: Weights, p: str, z: Tensor, layers: int, h: int, hd: i
         cache = w[f"{p}.freqs_cis"][:s]
     else:
         cache = ae_rope_cache(block_size, hd, rope_base)[:s]
+    cache = cache.to(x.device)
     mask = window_mask(s, window).to(x.device)
     for i in range(layers):
         lp = f"{p}.layers.{i}"

@@ -150,11 +150,22 @@ def _to_vt(v, pitch):
     return vt.contiguous()
 
 
-@pytest.mark.parametrize("S,Lt,Ls,use_bias", [(200, 70, 33, False), (128, 64, 128, True), (640, 436, 640, False)])
-def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias):
+@pytest.mark.parametrize("S,Lt,Ls,use_bias,spike", [(200, 70, 33, False, 0), (128, 64, 128, True, 0), (640, 436, 640, False, 0),
+                                                     (640, 436, 640, False, 2), (640, 436, 640, False, 20), (300, 64, 7, False, 20)])
+def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
+    """Joint attention over self | text | speaker segments with the CFG rows' segment switches, ragged segment ends and (use_bias)
+    an irregular key mask, against fp32 SDPA.  Without a bias the fast kernel (attn4_kernel: fixed softmax reference per stream)
+    runs; `spike` plants keys in a LATER tile whose score with one query is `spike` x |q|^2 (cdna guide rule 26: force the rare
+    branch): spike 2 stays inside the fast kernel's range (P up to 2^32 against the first tile's reference), spike 20 leaves it, so
+    the workgroup must be flagged and redone by attn_kernel with per-tile rescaling - that query's output is then one value row.
+    The default build runs attn_kernel (deferred rescale: the spikes force its rescale branch); tests/test_gpu_kernels.py::
+    test_attention_fast_kernel_variant repeats the spike cases in a child process with ECHO_ATTN4=1."""
     R, H = 3, 2
     q = rnd(R, S, H, 128, dtype=torch.bfloat16)
     k_self, v_self = rnd(R, S, H, 128, dtype=torch.bfloat16, seed=1), rnd(R, S, H, 128, dtype=torch.bfloat16, seed=2)
+    if spike:
+        k_self[0, min(S - 1, 150), 0] = (spike * q[0, 7, 0].float()).bfloat16()           # row 0, head 0: query 7 meets it in its third tile
+        k_self[1, S - 1, 1] = (spike * q[1, S - 2, 1].float()).bfloat16()                # row 1, head 1: in the last tile of the self segment
     k_t, v_t = rnd(1, Lt, H, 128, dtype=torch.bfloat16, seed=3), rnd(1, Lt, H, 128, dtype=torch.bfloat16, seed=4)
     k_s, v_s = rnd(1, Ls, H, 128, dtype=torch.bfloat16, seed=5), rnd(1, Ls, H, 128, dtype=torch.bfloat16, seed=6)
     gate = rnd(R, S, H * 128, dtype=torch.bfloat16, seed=7)
@@ -201,6 +212,18 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias):
     err = (out.float() - ref.reshape(R, S, H * 128)).abs()
     assert float(err.max()) < 3e-2, float(err.max())
     assert float(err.mean()) < 2e-3, float(err.mean())
+
+
+def test_attention_fast_kernel_variant():
+    """attn4_kernel (ECHO_ATTN4=1, read once per process): the joint-segment cases incl. the range-fallback spikes, in a child process."""
+    import os, subprocess, sys
+    if os.environ.get("ECHO_ATTN4") == "1":
+        pytest.skip("already the variant run")
+    env = dict(os.environ, ECHO_ATTN4="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "joint_segments or deterministic_at_full_size"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("S", [100, 256])
