@@ -271,8 +271,9 @@ def main() -> None:
         try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected inside this process)
             if args.c5:
                 raise RuntimeError("the PMC passes were taken on the C2 command")
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
-            traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm.json (2 x FETCH_SIZE + WRITE_SIZE, KiB; rocprofv3 --pmc passes of this command at the default batch)"
+            pmf = next(f for f in ("r02_pmc_gemm.json", "r01_pmc_gemm.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
+            traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), f"profiles/{pmf} (2 x FETCH_SIZE + WRITE_SIZE, KiB; rocprofv3 --pmc passes of this command at the default batch)"
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (" + ("fp8-e4m3" if args.c5 else "bf16") + " 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
