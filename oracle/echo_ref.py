@@ -158,9 +158,34 @@ def lowrank_adaln(w: Weights, p: str, x: Tensor, cond: Tensor, eps: float) -> Tu
     return x.to(dt), torch.tanh(gate)
 
 
+# BASELINE config C5 ("fp8 MFMA weight path for DiT GEMMs") has no counterpart in the reference; this is the restatement of the
+# algorithm the HIP engine's fp8 mode states: the four large linears of every EchoDiT block take OCP e4m3 operands,
+# weights scaled per output row and activations per token row by amax / 448, products accumulated in fp32, result rounded to the
+# model dtype.  Off by default; tests switch it on to pin the engine's fp8 path to something other than itself.
+_FP8_BLOCK_LINEARS = False
+
+
+def set_fp8_block_linears(on: bool) -> None:
+    global _FP8_BLOCK_LINEARS
+    _FP8_BLOCK_LINEARS = bool(on)
+
+
+def fake_quant_rows_e4m3(x: Tensor) -> Tensor:
+    xf = x.float()
+    s = xf.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30) / 448.0
+    return (xf / s).to(torch.float8_e4m3fn).float() * s
+
+
+def block_linear(x: Tensor, wt: Tensor, p: str) -> Tensor:
+    """nn.Linear of an EchoDiT block (attention wq / wk / wv / gate / wo, mlp w1 / w3 / w2); fp8 operands when C5 mode is on."""
+    if _FP8_BLOCK_LINEARS and p.startswith("blocks."):
+        return (fake_quant_rows_e4m3(x) @ fake_quant_rows_e4m3(wt).t()).to(x.dtype)
+    return F.linear(x, wt)
+
+
 def swiglu(w: Weights, p: str, x: Tensor) -> Tensor:
     """w2(silu(w1 x) * w3 x).  model.py:307-308."""
-    return F.linear(F.silu(F.linear(x, w[f"{p}.w1.weight"])) * F.linear(x, w[f"{p}.w3.weight"]), w[f"{p}.w2.weight"])
+    return block_linear(F.silu(block_linear(x, w[f"{p}.w1.weight"], p)) * block_linear(x, w[f"{p}.w3.weight"], p), w[f"{p}.w2.weight"], p)
 
 
 def encoder_self_attention(w: Weights, p: str, x: Tensor, mask: Optional[Tensor], fc: Tensor,
@@ -180,7 +205,7 @@ def encoder_self_attention(w: Weights, p: str, x: Tensor, mask: Optional[Tensor]
         query=q.transpose(1, 2), key=k.transpose(1, 2), value=v.transpose(1, 2), attn_mask=am, is_causal=causal
     ).transpose(1, 2)
     o = o.reshape(b, s, -1) * torch.sigmoid(g)
-    return F.linear(o, w[f"{p}.wo.weight"])
+    return block_linear(o, w[f"{p}.wo.weight"], p)
 
 
 def encoder_block(w: Weights, p: str, x: Tensor, mask: Optional[Tensor], fc: Tensor,
@@ -259,12 +284,12 @@ def joint_attention(w: Weights, cfg: DiTConfig, p: str, x: Tensor, text_mask: Te
     """JointAttention.forward: keys = [self | latent | text | speaker].  model.py:204-268."""
     b, s = x.shape[:2]
     h = cfg.num_heads
-    q = F.linear(x, w[f"{p}.wq.weight"]).reshape(b, s, h, -1)
-    k = F.linear(x, w[f"{p}.wk.weight"]).reshape(b, s, h, -1)
-    v = F.linear(x, w[f"{p}.wv.weight"]).reshape(b, s, h, -1)
+    q = block_linear(x, w[f"{p}.wq.weight"], p).reshape(b, s, h, -1)
+    k = block_linear(x, w[f"{p}.wk.weight"], p).reshape(b, s, h, -1)
+    v = block_linear(x, w[f"{p}.wv.weight"], p).reshape(b, s, h, -1)
     q = rms_norm(q, w[f"{p}.q_norm.weight"], cfg.norm_eps)
     k = rms_norm(k, w[f"{p}.k_norm.weight"], cfg.norm_eps)
-    g = F.linear(x, w[f"{p}.gate.weight"])
+    g = block_linear(x, w[f"{p}.gate.weight"], p)
     fq = fc[start_pos:start_pos + s]
     q = rotate_first_half_of_heads(q, fq)
     k = rotate_first_half_of_heads(k, fq)
@@ -286,7 +311,7 @@ def joint_attention(w: Weights, cfg: DiTConfig, p: str, x: Tensor, text_mask: Te
         query=q.transpose(1, 2), key=kk.transpose(1, 2), value=vv.transpose(1, 2), attn_mask=m, is_causal=False
     ).transpose(1, 2)
     o = o.reshape(b, s, -1) * torch.sigmoid(g)
-    return F.linear(o, w[f"{p}.wo.weight"])
+    return block_linear(o, w[f"{p}.wo.weight"], p)
 
 
 def dit_forward(w: Weights, cfg: DiTConfig, x: Tensor, t: Tensor, text_mask: Tensor, speaker_mask: Tensor,
@@ -651,15 +676,19 @@ def _wn_conv1x1(w: Weights, p: str, x: Tensor) -> Tensor:
     return F.conv1d(x, fold_weight_norm(w, p), w[f"{p}.bias"])
 
 
-def vq_forward(w: Weights, p: str, z: Tensor) -> Tuple[Tensor, Tensor]:
+def vq_forward(w: Weights, p: str, z: Tensor, gaps: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """VectorQuantize.forward (eval): in_proj, nearest L2-normalised code, straight-through value, out_proj.
-    Returns (z_q (B, D, T), indices (B, T)).  autoencoder.py:130-158."""
+    Returns (z_q (B, D, T), indices (B, T)).  autoencoder.py:130-158.  `gaps` (tests): receives per frame the distance margin
+    between the chosen code and the runner-up, i.e. how close the argmax is to a tie."""
     z_e = _wn_conv1x1(w, f"{p}.in_proj", z)
     b, d, t = z_e.shape
     enc = F.normalize(z_e.permute(0, 2, 1).reshape(b * t, d))
     cb = F.normalize(w[f"{p}.codebook.weight"])
     dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
     idx = (-dist).max(1)[1].view(b, t)
+    if gaps is not None:
+        top2 = (-dist).topk(2, dim=1)[0]
+        gaps.append((top2[:, 0] - top2[:, 1]).view(b, t))
     z_q = F.embedding(idx, w[f"{p}.codebook.weight"]).transpose(1, 2)
     z_q = z_e + (z_q - z_e)
     return _wn_conv1x1(w, f"{p}.out_proj", z_q), idx
@@ -690,13 +719,16 @@ def dac_encode_codes(w: Weights, cfg: DacConfig, audio: Tensor, taps: Optional[D
     z = post_module(w, cfg, z, "quantizer.pre_module")
     if taps is not None:
         taps["pre_module"] = z.clone()
-    sem_z, sem_idx = vq_forward(w, "quantizer.semantic_quantizer.quantizers.0", z)
+    gaps: Optional[List[Tensor]] = [] if taps is not None else None
+    sem_z, sem_idx = vq_forward(w, "quantizer.semantic_quantizer.quantizers.0", z, gaps)
     residual = z - sem_z
     codes = [sem_idx]
     for i in range(cfg.n_codebooks):
-        zq_i, idx_i = vq_forward(w, f"quantizer.quantizer.quantizers.{i}", residual)
+        zq_i, idx_i = vq_forward(w, f"quantizer.quantizer.quantizers.{i}", residual, gaps)
         residual = residual - zq_i
         codes.append(idx_i)
+    if taps is not None:
+        taps["vq_gap"] = torch.stack(gaps, dim=1)          # (B, 1 + n_codebooks, T): argmax margin of every stage
     return torch.stack(codes, dim=1)
 
 

@@ -232,9 +232,11 @@ def _enc_weights(cfg):
 
 
 def _check_encode(g, tag, cfg, n_samples, min_code_match):
-    """codes: index work is bit-exact wherever the argmax is not a near-tie (the split3 fp32 GEMM sums in a different order
-    than the CPU reference, so a frame whose two best codes differ by ~1e-6 may flip; such a frame then carries a different
-    but equally near code vector); z_q / latents: compared on the frames whose codes all agree."""
+    """codes: index work must be bit-exact (measured: 100 % on both fixtures).  The only legitimate difference is a near-tie of
+    the argmax: the split3 fp32 GEMM sums in a different order than the CPU reference, so a frame whose two best codes are closer
+    than fp32 noise may flip, and its later residual stages then see another input.  So for every frame that differs, the FIRST
+    stage that differs must be such a near-tie in the oracle (distance margin < 1e-5 on unit vectors); anything else fails.
+    z_q / latents: compared on the frames whose codes all agree."""
     dac = E.DAC(cfg, _enc_weights(cfg), device=DEV)
     audio = R.make_test_audio(n_samples, seed=11)
     codes, lens = dac.encode(audio)
@@ -243,6 +245,14 @@ def _check_encode(g, tag, cfg, n_samples, min_code_match):
     same = (codes.cpu() == ref_codes)
     frac = float(same.float().mean())
     assert frac >= min_code_match, frac
+    if frac < 1.0:
+        taps = {}
+        torch.set_num_threads(16)
+        assert torch.equal(R.dac_encode_codes(_enc_weights(cfg), cfg, audio, taps), ref_codes)
+        gap = taps["vq_gap"]
+        for b, t in (~same.all(dim=1)).nonzero().tolist():
+            k = int((~same[b, :, t]).nonzero()[0])
+            assert float(gap[b, k, t]) < 1e-5, f"{tag}: frame {t} differs first at stage {k} where the oracle's argmax margin is {float(gap[b, k, t]):.3e}"
     ok = same.all(dim=1)[0]                                   # frames with every code equal
     zq = dac.encode_zq(audio).cpu()
     ref_zq = g[f"{tag}.zq"]
@@ -259,7 +269,7 @@ def _check_encode(g, tag, cfg, n_samples, min_code_match):
 
 def test_dac_encode_tiny_matches_reference(golden):
     from tests.golden_defs import TINY_ENC_SAMPLES
-    dac, st, audio, frac = _check_encode(golden, "enc_tiny", TINY_DAC, TINY_ENC_SAMPLES, 0.95)
+    dac, st, audio, frac = _check_encode(golden, "enc_tiny", TINY_DAC, TINY_ENC_SAMPLES, 0.99)
     lat, mask = E.get_speaker_latent_and_mask(dac, st, audio[0].to(DEV), max_speaker_latent_length=24, audio_chunk_size=4 * 2048)
     assert lat.shape == golden["enc_tiny.spk_latent"].shape and torch.equal(mask.cpu().to(torch.uint8), golden["enc_tiny.spk_mask"])
     if frac == 1.0:
@@ -269,7 +279,7 @@ def test_dac_encode_tiny_matches_reference(golden):
 def test_dac_encode_full_size_matches_reference(golden):
     """Full-size encoder: 4-layer window-512 transformer over 600 positions, pre_module, VQ 4096 + 9 x 1024."""
     from tests.golden_defs import FULL_ENC_SAMPLES
-    _check_encode(golden, "enc_full", R.DacConfig(), FULL_ENC_SAMPLES, 0.97)
+    _check_encode(golden, "enc_full", R.DacConfig(), FULL_ENC_SAMPLES, 0.99)
 
 
 def test_dac_encode_is_causal(golden):
@@ -628,6 +638,35 @@ def test_fp8_mfma_engine_c5(golden, tiny_models):
     rel = rms(outs[0], outs[1]) / U.rms(outs[0])
     print(f"C5 (full width, 1 layer): fp8 forward vs bf16 forward: relative rms {rel:.3e}")
     assert rel < 0.1, rel
+
+
+def test_fp8_engine_against_fake_quant_restatement(golden):
+    """BASELINE config C5 pinned to something other than itself.  The reference has no fp8 path (parity with the reference:
+    unpinned by nature), but the algorithm the fp8 engine states - e4m3 operands for the four block linears, one scale per weight
+    row and per token row (amax / 448), fp32 accumulation, bf16 tails - is restated in the oracle (`set_fp8_block_linears`).  One
+    velocity prediction at FULL width (one layer of each stack) and on the tiny model: the engine must be much closer to that
+    restatement than the restatement is to plain bf16 (fp8's own effect), i.e. it really computes the stated arithmetic."""
+    for cfg, S, T in ((WIDE1, 200, 40), (TINY, 32, 24)):
+        wb = {k: v.bfloat16() for k, v in R.make_dit_weights(cfg, seed=0).items()}
+        gen = torch.Generator().manual_seed(3)
+        ids = torch.randint(1, 256, (1, T), generator=gen, dtype=torch.int32)
+        tmask = torch.ones((1, T), dtype=torch.bool)
+        spk, smask = torch.randn((1, 64, 80), generator=gen).bfloat16(), torch.ones((1, 64), dtype=torch.bool)
+        x = torch.randn((1, S, 80), generator=gen).bfloat16()
+        t = torch.full((1,), 0.75).bfloat16()
+        m8 = E.EchoDiT(cfg, wb, dtype=torch.bfloat16, device=DEV, fp8=True)
+        got = m8(x, t, tmask, smask, m8.get_kv_cache_text(ids, tmask), m8.get_kv_cache_speaker(spk, smask)).float().cpu()
+        kvt, kvs = R.kv_cache_text(wb, cfg, ids, tmask), R.kv_cache_speaker(wb, cfg, spk)
+        plain = R.dit_forward(wb, cfg, x, t, tmask, smask, kvt, kvs)
+        R.set_fp8_block_linears(True)
+        try:
+            want = R.dit_forward(wb, cfg, x, t, tmask, smask, kvt, kvs)
+        finally:
+            R.set_fp8_block_linears(False)
+        e, effect = rms(got, want), rms(want, plain)
+        print(f"C5 fp8 engine vs fake-quant restatement (d = {cfg.model_size}): rms {e:.3e}; fp8's own effect (restatement vs bf16) {effect:.3e}; "
+              f"output rms {U.rms(want):.3f}")
+        assert effect > 0 and e < 0.5 * effect + 2e-3 * U.rms(want), (e, effect)
 
 
 def test_voice_cloning_pipeline_from_audio(golden, tiny_models):
