@@ -21,7 +21,12 @@ single-request configuration (C2 proper); its throughput is measured in the same
 as a serving process does with independent requests (handler.py:747-759): the second call's kernels fill the CUs that
 the last, partial round of 256x256 tiles of the first leaves idle (+6 % measured; `--concurrency 1` for one call).
 Measured sweep (audio-s/s, batch x concurrency, round-1 v7 binaries): 1x1 97, 4x1 134, 4x2 148, 8x2 157, 12x2 160, 16x2 161;
-v11 binaries: 8x2 164-172.
+round 2: 8x2 169-173, 12x2 172.6, 16x2 172.9, 8x3 169.6.
+
+Next to the headline the line carries: `single_request` (C2 proper: one utterance per call), `c3_share` (C3's per-GPU share: 4 per
+call, one call in flight), `cpu_baseline` (the oracle on the host cores, real 24-layer model) and `eager_gpu_baseline` (the oracle's
+torch ops run eagerly through PyTorch-ROCm on the same GPU: the reference's own execution model).  The one reference voice is encoded
+once per sampler call, inside the timed region, and shared by the call's rows.
 
 Multi-GPU: independent utterances shard data-parallel (weak scaling: every rank runs `steps`
 utterances); the only collective in the job is the start-up broadcast of the frozen weights from

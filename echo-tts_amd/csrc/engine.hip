@@ -1404,6 +1404,8 @@ struct Engine : EngineBase {
       }
       if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
       gemm_event_flops[gemm_events_used] = 0.0;
+      if (gemm_event_shape.size() < gemm_events.size()) gemm_event_shape.resize(gemm_events.size());
+      gemm_event_shape[gemm_events_used] = {g.M, g.N, g.K, g.taps, g.swiglu, g.qkv_mode, g.fp8, g.cfg, g.ksplit, g.nbatch};
       auto& e = gemm_events[gemm_events_used++];
       CK(hipEventRecord(e.first, st));
       CK(launch_gemm_nt<float>(g, st));
