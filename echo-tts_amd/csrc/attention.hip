@@ -471,6 +471,29 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// max of s[h .. h + 7] as one statement: hipcc pads a wait state behind every asm statement whose output a VALU reads next
+__device__ __forceinline__ float max8(const f32x16& s, int h) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+      : "=&v"(r) : "v"(s[h]), "v"(s[h + 1]), "v"(s[h + 2]), "v"(s[h + 3]), "v"(s[h + 4]), "v"(s[h + 5]), "v"(s[h + 6]), "v"(s[h + 7]));
+  return r;
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {   // no canonicalising v_max in front (fmaxf on an MFMA / asm result gets one)
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// Score MFMAs in the VGPR form (D / C in arch VGPRs, Q in the accumulator file): the softmax reads the scores with the vector ALU, and
+// hipcc's AGPR-form chain costs a v_accvgpr_read per element (80 of the 488 VALU issues of a step).  hipcc pads no hazards of an asm
+// MFMA (cdna_hip_programming.md §5.7 item 2): the first reader of a finished chain is a softmax slot at least two MFMA issues
+// (>= 64 cycles) later by construction of the phases - audit the ISA for compiler v_mov of these registers after every edit.
+__device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& kf, const bf16x8& q) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_s_next(f32x16& s, const bf16x8& kf, const bf16x8& q) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(q));
+}
+
 // LDS fragment read hidden from hipcc's wait-count bookkeeping (cdna_hip_programming.md §5.7 item 1, form iii): hipcc waits
 // lgkmcnt(0) in front of every third MFMA of a rolling three-fragment window - i.e. also for the read it has just issued - which
 // exposes a full LDS round trip 21 times per tile (measured: 2.7 us per tile instead of ~1.2).  Here every MFMA gap issues exactly
@@ -557,43 +580,37 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
     v_d[i] = (wid * 4 + i) * 8 + (lane >> 3);
     v_c[i] = ((lane & 7) ^ ((v_d[i] >> 1) & 7)) << 4;
   }
-  Stream ks, vs, cur;
+  // ONE tile walk, three readers: d2 = tile t + 2 (its K is staged during step t), d1 = tile t + 1 (its V), d0 = tile t (masking).
+  // Only d2 is advanced (one compare and two pointer increments on the common path, the segment switch out of line); d1 and d0 are
+  // last step's d2 and d1.  All scalar: every wave computes the same values.
+  struct Tile { int seg, k0, nk; const char* kptr; const char* vptr; int kstep; };
+  Tile d2, d1;
+  int d0_valid = 0, vseg = -1;
   unsigned k_off[4], v_off[4];
   auto k_offsets = [&]() {
-    const int kld = (int)SEL4(kld_, ks.seg), last = ks.nk - 1 - ks.k0;      // rows past the segment's last key repeat it (masked by cz)
+    const int kld = (int)SEL4(kld_, d2.seg), last = d2.nk - 1 - d2.k0;      // rows past the segment's last key repeat it (masked in the softmax)
 #pragma unroll
     for (int i = 0; i < 4; ++i) k_off[i] = (unsigned)(min(k_r[i], last) * kld + k_c[i]);
   };
-  auto k_enter = [&](int sg) {
-    ks.seg = sg; ks.k0 = 0; ks.nk = NK(sg); ks.ptr = SEL4(kb_, sg); ks.step = (int)SEL4(kld_, sg) * KT;
+  auto enter = [&](int sg) {
+    d2.seg = sg; d2.k0 = 0; d2.nk = NK(sg); d2.kptr = SEL4(kb_, sg); d2.vptr = SEL4(vb_, sg); d2.kstep = (int)SEL4(kld_, sg) * KT;
     k_offsets();
   };
-  auto k_advance = [&]() {                       // past the end the stream stays on the last tile
-    if (ks.k0 + KT < ks.nk) {
-      ks.k0 += KT; ks.ptr += ks.step;
-      if (ks.k0 + KT > ks.nk) k_offsets();
-    } else {
-      const int sg = next_seg(ks.seg);
-      if (sg < 4) k_enter(sg);
+  auto advance = [&]() {                         // past the end the walk stays on the last tile
+    if (__builtin_expect(d2.k0 + 2 * KT <= d2.nk, 1)) { d2.k0 += KT; d2.kptr += d2.kstep; d2.vptr += KT * 2; }
+    else if (d2.k0 + KT < d2.nk) { d2.k0 += KT; d2.kptr += d2.kstep; d2.vptr += KT * 2; k_offsets(); }
+    else { const int sg = next_seg(d2.seg); if (sg < 4) enter(sg); }
+  };
+  auto v_offsets = [&]() {                       // per-lane offsets of the V^T pieces of d1's segment
+    if (__builtin_expect(d1.seg != vseg, 0)) {
+      vseg = d1.seg;
+      const int vld = (int)SEL4(vld_, d1.seg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v_off[i] = (unsigned)(v_d[i] * vld + v_c[i]);
     }
   };
-  auto v_enter = [&](int sg) {
-    vs.seg = sg; vs.k0 = 0; vs.nk = NK(sg); vs.ptr = SEL4(vb_, sg); vs.step = KT * 2;
-    const int vld = (int)SEL4(vld_, sg);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v_off[i] = (unsigned)(v_d[i] * vld + v_c[i]);
-  };
-  auto v_advance = [&]() {
-    if (vs.k0 + KT < vs.nk) { vs.k0 += KT; vs.ptr += vs.step; }
-    else { const int sg = next_seg(vs.seg); if (sg < 4) v_enter(sg); }
-  };
-  auto c_enter = [&](int sg) { cur.seg = sg; cur.k0 = 0; cur.nk = NK(sg); };
-  auto c_advance = [&]() {
-    if (cur.k0 + KT < cur.nk) cur.k0 += KT;
-    else { const int sg = next_seg(cur.seg); if (sg < 4) c_enter(sg); }
-  };
-  auto dma_k = [&](int i, char* kdst) __attribute__((always_inline)) { glds16(ks.ptr + k_off[i], kdst + i * 1024); };
-  auto dma_v = [&](int i, char* vdst) __attribute__((always_inline)) { glds16(vs.ptr + v_off[i], vdst + i * 1024); };
+  auto dma_k = [&](int i, char* kdst) __attribute__((always_inline)) { glds16(d2.kptr + k_off[i], kdst + i * 1024); };
+  auto dma_v = [&](int i, char* vdst) __attribute__((always_inline)) { glds16(d1.vptr + v_off[i], vdst + i * 1024); };
 
   const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped (see attn_kernel)
   const int sw_v = (lane >> 1) & 7;
@@ -626,7 +643,8 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
     for (int i = 0; i < 4; ++i) { st[qb].pf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; st[qb].mxp[i] = 0.f; st[qb].rs[i] = 0.f; }
   }
   int ovf = 0;             // a score left the fixed reference's range (wave-uniform)
-  f32x16 cz[2];            // start value of the score chains of the current tile: 0 / -inf per key (see header)
+  bool ragged = false;     // the current tile has fewer than KT valid keys (wave-uniform)
+  float mask_x = 0.0f;     // valid keys of the current tile - 8 fh
 
   // ---- softmax of stream q, cut into 32 slots that ride in the MFMA gaps of the other stream
   auto soft_slot = [&](auto qc_, auto ic_) __attribute__((always_inline)) {
@@ -634,11 +652,21 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
     Soft& S = st[q];
     if constexpr (I < 4) {
       constexpr int kb = I >> 1, h = 8 * (I & 1);
-      const float a = fmaxf(fmaxf(S.s[kb][h], S.s[kb][h + 1]), S.s[kb][h + 2]);
-      const float b = fmaxf(fmaxf(S.s[kb][h + 3], S.s[kb][h + 4]), S.s[kb][h + 5]);
-      S.mxp[I] = fmaxf(fmaxf(a, b), fmaxf(S.s[kb][h + 6], S.s[kb][h + 7]));
+      if (__builtin_expect(ragged, 0)) {            // keys past the segment's end: a hugely negative addend (wave-uniform, the last tile of a segment only)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float mk = fminf(0.0f, __builtin_fmaf(mask_x, 1e30f, -((float)(32 * kb + 16 * ((h + j) >> 3) + ((h + j) & 7)) + 0.5f) * 1e30f));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(S.s[kb][h + j]) : "v"(mk));
+        }
+      }
+      if constexpr (DIAG & 32) {
+        const float a = fmaxf(fmaxf(S.s[kb][h], S.s[kb][h + 1]), S.s[kb][h + 2]);
+        const float b = fmaxf(fmaxf(S.s[kb][h + 3], S.s[kb][h + 4]), S.s[kb][h + 5]);
+        S.mxp[I] = fmaxf(fmaxf(a, b), fmaxf(S.s[kb][h + 6], S.s[kb][h + 7]));
+      } else S.mxp[I] = max8(S.s[kb], h);
     } else if constexpr (I == 4) {
-      S.mxp[0] = half_max(fmaxf(fmaxf(S.mxp[0], S.mxp[1]), fmaxf(S.mxp[2], S.mxp[3])));
+      if constexpr (DIAG & 32) S.mxp[0] = half_max(fmaxf(fmaxf(S.mxp[0], S.mxp[1]), fmaxf(S.mxp[2], S.mxp[3])));
+      else S.mxp[0] = half_max(max3(max3(S.mxp[0], S.mxp[1], S.mxp[2]), S.mxp[3], S.mxp[3]));
     } else if constexpr (I == 5) {
       const float mx = S.mxp[0];
       S.m = S.m == -1e30f ? mx : S.m;                        // the first tile sets the reference; O and l are still 0
@@ -694,16 +722,27 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
       if constexpr (DIAG & 2) asm volatile("" :: "v"(fq[g % FW]));
       else if constexpr (KIND == 0) {
         constexpr int kb = g >> 3, kk = g & 7;
-        if constexpr (kk == 0) st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], cz[kb], 0, 0, 0);
-        else st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], st[q].s[kb], 0, 0, 0);
+        if constexpr (DIAG & 16) {
+          if constexpr (kk == 0) st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+          else st[q].s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], qf[q][kk], st[q].s[kb], 0, 0, 0);
+        } else if constexpr (kk == 0) mfma_s_first(st[q].s[kb], fq[g % FW], qf[q][kk]);
+        else mfma_s_next(st[q].s[kb], fq[g % FW], qf[q][kk]);
       } else {
         constexpr int kss = g >> 2, db = g & 3;
         o[q][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[g % FW], st[q].pf[kss], o[q][db], 0, 0, 0);
       }
+      if constexpr (!(DIAG & 64)) __builtin_amdgcn_sched_barrier(0);          // the gap's vector work stays BEHIND its MFMA (hipcc hoisted it in front of every second one)
       if constexpr (VQ >= 0 && !(DIAG & 1)) soft_slot(std::integral_constant<int, (VQ < 0 ? 0 : VQ)>{}, std::integral_constant<int, SL0 + g>{});
       if constexpr (DMA && (g & 1) == 0 && !(DIAG & 4)) { if constexpr (g < 8) dma_k(g >> 1, kdst); else dma_v((g - 8) >> 1, vdst); }
       __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  // The look-ahead reads at the end of the LAST step (and of the drain) have no consumer: without a use behind the wait hipcc treats
+  // their destination registers as free while the reads are still in flight and puts live values there (seen: exponentials of
+  // stream 1 overwritten by the late LDS return whenever total_tiles % 3 == 2).  A use of the whole window behind every wait.
+  auto keep_window = [&]() __attribute__((always_inline)) {
+    static_assert(FW == 8, "lists the whole window");
+    asm volatile("" ::"v"(fq[0]), "v"(fq[1]), "v"(fq[2]), "v"(fq[3]), "v"(fq[4]), "v"(fq[5]), "v"(fq[6]), "v"(fq[7]));
   };
   typedef std::integral_constant<int, 0> I0;
   typedef std::integral_constant<int, 1> I1;
@@ -714,21 +753,23 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
     {
       int s0 = 0;
       while (s0 < 3 && NK(s0) == 0) ++s0;
-      k_enter(s0); v_enter(s0); c_enter(s0);
+      enter(s0);
     }
+    d1 = d2; v_offsets();
+    d0_valid = d2.nk - d2.k0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_k(i, kring + wid * 4096);                          // K(0) -> K slot 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_v(i, vring + wid * 4096);                          // V(0) -> V slot 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_v(i, vring + 2 * V_TILE_BYTES + wid * 4096);       // and -> V slot 2: finite operands for PV1(-1), whose P is 0
-    k_advance();
+    advance();                        // d2 = tile 1
     if (total_tiles > 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_k(i, kring + K_TILE_BYTES + wid * 4096);         // K(1) -> K slot 1
     }
-    k_advance();                      // ks -> tile 2, vs -> tile 1, cur = tile 0
-    v_advance();
+    d1 = d2; v_offsets();             // d1 = tile 1
+    advance();                        // d2 = tile 2
     // step t (slot sl = t % 3, a literal): reads K(t) [K slot sl], V(t-1) [V slot sl + 2], V(t) [V slot sl]; stages K(t+2) -> K slot
     // sl + 2 and V(t+1) -> V slot sl + 1.  The fragment window enters phase j of step sl at offset (4 sl + j) % 3 = (sl + j) % 3.
     auto step = [&](const int sl) __attribute__((always_inline)) {
@@ -740,26 +781,21 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
       char* kdst = kring + sl2 * K_TILE_BYTES + wid * 4096;
       char* vdst = vring + sl1 * V_TILE_BYTES + wid * 4096;
       if (wave_on) {
-        // cz = 0 for key < vk (valid keys of tile t; >= 64: all), hugely negative otherwise: min(0, (vk - key - 0.5) * 1e30) with the
-        // lane part of the key index folded into x - two VALU operations per element, no VCC round trip
-        const float x = (float)(cur.nk - cur.k0 - 8 * fh);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            cz[kb][r] = fminf(0.0f, __builtin_fmaf(x, 1e30f, -((float)(32 * kb + 16 * (r >> 3) + (r & 7)) + 0.5f) * 1e30f));
+        ragged = d0_valid < KT;
+        mask_x = (float)(d0_valid - 8 * fh);
         phase(I0{}, I0{}, sl, sl2, I1{}, I16{}, I1{}, kdst, vdst);     // S0(t)    | softmax 1 (t-1), slots 16-31   (next: PV1(t-1) from V slot sl2)
         phase(I1{}, I1{}, sl2, sl, I0{}, I0{}, I0{}, kdst, vdst);      // PV1(t-1) | softmax 0 (t),   slots 0-15    (next: S1(t)    from K slot sl)
         phase(I0{}, I1{}, sl, sl, I0{}, I16{}, I0{}, kdst, vdst);      // S1(t)    | softmax 0 (t),   slots 16-31   (next: PV0(t)   from V slot sl)
         phase(I1{}, I0{}, sl, sl1, I1{}, I0{}, I0{}, kdst, vdst);      // PV0(t)   | softmax 1 (t),   slots 0-15    (next: S0(t+1)  from K slot sl1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the next step's S0: back in hipcc's books
+        keep_window();
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_k(i, kdst);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_v(i, vdst);
       }
-      k_advance(); v_advance(); c_advance();
+      d0_valid = d1.nk - d1.k0; d1 = d2; v_offsets(); advance();
     };
     // the first two fragments of S0(0): K(0) has to be visible to every wave first
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -782,6 +818,7 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         phase(I1{}, I1{}, vsl, 0, IN{}, I0{}, I0{}, kring, vring);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        keep_window();
       };
       if (last == 0) drain(0); else if (last == 1) drain(1); else drain(2);
     }
@@ -849,9 +886,9 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     // for the (normally zero) workgroups whose scores left the fast kernel's range; both on the caller's stream
     static std::atomic<unsigned long long> prep4[8];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
-    const int di = diag == 1 ? 1 : diag == 2 ? 2 : diag == 3 ? 3 : diag == 7 ? 4 : diag == 11 ? 5 : diag == 15 ? 6 : diag == 4 ? 7 : 0;
+    const int di = diag == 1 ? 1 : diag == 2 ? 2 : diag == 3 ? 3 : diag == 7 ? 4 : diag == 48 ? 5 : diag == 112 ? 6 : diag == 16 ? 7 : 0;
     const void* k4[8] = {(const void*)attn4_kernel<0>, (const void*)attn4_kernel<1>, (const void*)attn4_kernel<2>, (const void*)attn4_kernel<3>,
-                         (const void*)attn4_kernel<7>, (const void*)attn4_kernel<11>, (const void*)attn4_kernel<15>, (const void*)attn4_kernel<4>};
+                         (const void*)attn4_kernel<7>, (const void*)attn4_kernel<48>, (const void*)attn4_kernel<112>, (const void*)attn4_kernel<16>};
     if (hipError_t e = ensure_dyn_lds(k4[di], SMEM4, prep4[di]); e != hipSuccess) return e;
     const dim3 g4((a.S + 255) / 256, a.H, a.rows);
     switch (di) {
@@ -859,9 +896,9 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
       case 2: hipLaunchKernelGGL(attn4_kernel<2>, g4, dim3(256), SMEM4, st, a); break;
       case 3: hipLaunchKernelGGL(attn4_kernel<3>, g4, dim3(256), SMEM4, st, a); break;
       case 4: hipLaunchKernelGGL(attn4_kernel<7>, g4, dim3(256), SMEM4, st, a); break;
-      case 5: hipLaunchKernelGGL(attn4_kernel<11>, g4, dim3(256), SMEM4, st, a); break;
-      case 6: hipLaunchKernelGGL(attn4_kernel<15>, g4, dim3(256), SMEM4, st, a); break;
-      case 7: hipLaunchKernelGGL(attn4_kernel<4>, g4, dim3(256), SMEM4, st, a); break;
+      case 5: hipLaunchKernelGGL(attn4_kernel<48>, g4, dim3(256), SMEM4, st, a); break;
+      case 6: hipLaunchKernelGGL(attn4_kernel<112>, g4, dim3(256), SMEM4, st, a); break;
+      case 7: hipLaunchKernelGGL(attn4_kernel<16>, g4, dim3(256), SMEM4, st, a); break;
       default: hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
