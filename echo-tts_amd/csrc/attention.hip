@@ -862,6 +862,410 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
   }
 }
 
+// =====================================================================================================================================
+// attn5_kernel: 4 waves x 64 queries like attn4_kernel, but the two 32-query streams of a wave run in LOCKSTEP and share every LDS
+// fragment: one ds_read_b128 feeds two MFMAs (stream 0 and stream 1).  attn4_kernel (and attn_kernel) read one 1 KiB fragment per
+// MFMA: 4 waves x 1 KiB / 32 cycles = 128 B/clk/CU, the whole LDS bandwidth - its "no MFMA, no softmax" ablation build still takes
+// 120-147 us of the 250.  Here it is 64 B/clk.
+//   step t:   A(t+1): S0,S1(t+1) = K(t+1) Q0^T, K(t+1) Q1^T   (16 K fragments, 32 MFMAs)  | second half of softmax(t), both streams
+//             B(t):   O0,O1 += V^T(t) P0,P1(t)                 (16 V fragments, 32 MFMAs)  | first half of softmax(t+1)
+// Scores are double-buffered in arch VGPRs (asm MFMAs in the VGPR form: 2 x 64 registers), P is packed in place of the consumed
+// scores' successors (32 registers), O (128), Q (64) and a 16-fragment window of K / V^T fragments (64, written by ds_read directly)
+// fill the accumulator file.  Softmax slots, fixed reference + range fallback, masking and the tile walk are attn4_kernel's.
+// Rings: K four tiles, V^T three: step t stages K(t+4) and V^T(t+2), i.e. every tile two steps before its first reader (the look-ahead
+// reads at the end of step t already touch K(t+2)), so the per-step wait is vmcnt(8) - the previous step's eight pieces stay in flight.
+// Ring slots are not literals (the loop is unrolled by two, for the score buffers): the eight K and four V^T read addresses move by
+// one v_add each per step.  No LGKM drain at a step's end: the eight look-ahead reads stay in flight across the barrier.
+// The last step computes a dummy A(T) (the walk stays on the last tile): 32 MFMAs per workgroup.
+constexpr int K5_SLOTS = 4, V5_SLOTS = 3;
+constexpr int SMEM5 = K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16;
+
+__device__ __forceinline__ bf16x8 lds_read16a(unsigned addr, int off) {      // LDS -> accumulator file
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "i"(off));
+  return v;
+}
+__device__ __forceinline__ void mfma_sa_first(f32x16& s, const bf16x8& kf, const bf16x8& q) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "a"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_sa_next(f32x16& s, const bf16x8& kf, const bf16x8& q) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "a"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_pv(f32x16& o, const bf16x8& vf, const bf16x8& pf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "a"(vf), "v"(pf));
+}
+
+// eight fp32 -> bf16x8 with exactly four v_cvt_pk_bf16_f32 (hipcc sometimes converts the elements one by one and merges with v_perm_b32)
+__device__ __forceinline__ bf16x8 pack8_asm(const f32x16& s, int base) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned u;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u) : "v"(s[base + 2 * j]), "v"(s[base + 2 * j + 1]));
+    r[j] = u;
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+struct Soft5 {           // softmax state of one query stream (the scores live in sc[buf][q][kb])
+  bf16x8 pf[4];          // P^T as the B operand of the four PV k-steps
+  float m, l, mc;
+  float mxp[4], rs[4];
+};
+
+// DIAG bits (timing experiments only, wrong results): 1 = no softmax VALU work, 2 = no MFMAs
+template <int DIAG>
+__global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [4][16 KiB] | V ring [3][16 KiB] | 4 range flags
+  constexpr int QW = 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.z, head = blockIdx.y;
+  const int qbase = blockIdx.x * QW;
+  const int fr = lane & 31, fh = lane >> 5;
+  const bool wave_on = qbase + wid * 64 < p.S;          // wave-uniform: a wave without queries only stages tiles
+  char* const kring = smem;
+  char* const vring = smem + K5_SLOTS * K_TILE_BYTES;
+  int* const wflags = (int*)(smem + K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES);
+
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = qbase + wid * 64 + qb * 32 + fr;
+    const int qc = qi < p.S ? qi : p.S - 1;
+    const bf16_t* qp = p.Q + (long)row * p.q_row_stride + (long)qc * p.q_ld + head * HD + 8 * fh;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + 16 * kk);
+  }
+
+  int nkraw[4];
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) nkraw[sgi] = (sgi < p.nseg ? p.seg[sgi].nkeys : p.seg[0].nkeys)[row];
+  auto seg_keys = [&](int sgi) __attribute__((always_inline)) -> int { const int nk = sgi < p.nseg ? nkraw[sgi] : 0; return nk < 0 ? 0 : nk; };
+  const int nk0 = seg_keys(0), nk1 = seg_keys(1), nk2 = seg_keys(2), nk3 = seg_keys(3);
+  auto NK = [&](int s) __attribute__((always_inline)) -> int { return s == 0 ? nk0 : s == 1 ? nk1 : s == 2 ? nk2 : s == 3 ? nk3 : 0; };
+  auto NT = [&](int s) __attribute__((always_inline)) -> int { return (NK(s) + KT - 1) / KT; };
+  const int total_tiles = NT(0) + NT(1) + NT(2) + NT(3);
+  const char* kb_[4]; const char* vb_[4]; int kld_[4], vld_[4];
+  int mod0 = 0;
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi)
+    if (sgi < p.nseg && mod0 == 0 && p.seg[sgi].kv_mod > 0) mod0 = p.seg[sgi].kv_mod;
+  const int rmod0 = mod0 > 0 ? row % mod0 : row;
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) {
+    kb_[sgi] = nullptr; vb_[sgi] = nullptr; kld_[sgi] = 0; vld_[sgi] = 0;
+    if (sgi < p.nseg) {
+      const AttnSeg& sg = p.seg[sgi];
+      const int kvrow = sg.kv_mod == 0 ? row : (sg.kv_mod == mod0 ? rmod0 : row % sg.kv_mod);
+      kb_[sgi] = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
+      vb_[sgi] = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
+      kld_[sgi] = (int)sg.k_ld * 2; vld_[sgi] = (int)sg.vt_ld * 2;
+    }
+  }
+  auto next_seg = [&](int sg) __attribute__((always_inline)) -> int { ++sg; while (sg < 4 && NK(sg) == 0) ++sg; return sg; };
+
+  // ---- the tile walk: w = tile t + 4 (its K is staged during step t), x3 = tile t + 3, x2 = tile t + 2 (its V^T is staged during step
+  // t), valid1 = key count of tile t + 1 (masks the first softmax half).  Only w is advanced; the others are last step's w, x3, x2.  DMA roles as in attn4_kernel;
+  // the per-lane role constants are recomputed where an offset changes (segment switch, ragged tile) instead of being kept in registers.
+  struct Tile { int seg, k0, nk; const char* kptr; const char* vptr; int kstep; };
+  struct Lag { int seg, valid; const char* vptr; };      // what the two followers need of a tile
+  Tile w;
+  Lag x3, x2;
+  int valid1 = 0;
+  auto lag_of = [&]() __attribute__((always_inline)) -> Lag { return Lag{w.seg, w.nk - w.k0, w.vptr}; };
+  int vseg = -1;
+  unsigned k_off[4], v_off[4];
+  auto k_offsets = [&]() __attribute__((always_inline)) {
+    const int kld = SEL4(kld_, w.seg), last = w.nk - 1 - w.k0;        // rows past the segment's last key repeat it (masked in the softmax)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wid * 4 + i) * 4 + (lane >> 4);
+      k_off[i] = (unsigned)(min(r, last) * kld + (((lane & 15) ^ (r & 15)) << 4));
+    }
+  };
+  auto enter = [&](int sg) __attribute__((always_inline)) {
+    w.seg = sg; w.k0 = 0; w.nk = NK(sg); w.kptr = SEL4(kb_, sg); w.vptr = SEL4(vb_, sg); w.kstep = SEL4(kld_, sg) * KT;
+    k_offsets();
+  };
+  auto advance = [&]() __attribute__((always_inline)) {                         // past the end the walk stays on the last tile
+    if (__builtin_expect(w.k0 + 2 * KT <= w.nk, 1)) { w.k0 += KT; w.kptr += w.kstep; w.vptr += KT * 2; }
+    else if (w.k0 + KT < w.nk) { w.k0 += KT; w.kptr += w.kstep; w.vptr += KT * 2; k_offsets(); }
+    else { const int sg = next_seg(w.seg); if (sg < 4) enter(sg); }
+  };
+  auto v_offsets = [&]() __attribute__((always_inline)) {                       // per-lane offsets of the V^T pieces of x2's segment
+    if (__builtin_expect(x2.seg != vseg, 0)) {
+      vseg = x2.seg;
+      const int vld = SEL4(vld_, x2.seg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = (wid * 4 + i) * 8 + (lane >> 3);
+        v_off[i] = (unsigned)(d * vld + (((lane & 7) ^ ((d >> 1) & 7)) << 4));
+      }
+    }
+  };
+  auto dma_k = [&](int i, char* kdst) __attribute__((always_inline)) { glds16(w.kptr + k_off[i], kdst + i * 1024); };
+  auto dma_v = [&](int i, char* vdst) __attribute__((always_inline)) { glds16(x2.vptr + v_off[i], vdst + i * 1024); };
+
+  const int pi_row = (fr & 0x13) | ((fr & 4) << 1) | ((fr & 8) >> 1);  // K rows are fed with bits 2,3 swapped (see attn_kernel)
+  const int sw_v = (lane >> 1) & 7;
+  const int sw_k = pi_row & 15;
+  unsigned ka[8], va[4];     // fragment read addresses incl. the CURRENT K / V ring slot (moved by kdelta / vdelta once per step)
+  {
+    const unsigned kbase = (unsigned)(unsigned long)(lptr_t)kring, vbase = (unsigned)(unsigned long)(lptr_t)vring;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ka[kk] = kbase + pi_row * 256 + (((2 * kk + fh) ^ sw_k) << 4);
+#pragma unroll
+    for (int kss = 0; kss < 4; ++kss) va[kss] = vbase + fr * 128 + (((2 * kss + fh) ^ sw_v) << 4);
+  }
+  const float c = p.scale * 1.4426950408889634f;
+  f32x16 o[2][4];            // accumulator file (asm "+a")
+  f32x16 sc[2][2][2];        // [buffer][stream][kb] scores / P of a tile: arch VGPRs (asm "=&v" / "+v")
+  Soft5 st[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
+    st[qb].m = -1e30f; st[qb].l = 0.0f; st[qb].mc = -1e30f * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st[qb].pf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; st[qb].mxp[i] = 0.f; st[qb].rs[i] = 0.f; }
+  }
+  int ovf = 0;             // a score left the fixed reference's range (wave-uniform)
+  bool ragged = false;     // the tile whose first softmax half runs has fewer than KT valid keys (wave-uniform)
+  int mask_l = 0;          // its valid keys - 8 fh
+
+  // ---- softmax of stream q on score buffer b, cut into 32 slots (attn4_kernel's): 0-15 = first half, 16-31 = second half
+  auto soft_slot = [&](auto qc_, auto bc_, auto ic_) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, I = decltype(ic_)::value;
+    Soft5& S = st[q];
+    f32x16 (&s)[2] = sc[b][q];
+    if constexpr (I < 4) {
+      constexpr int kb = I >> 1, h = 8 * (I & 1);
+      if (__builtin_expect(ragged, 0)) {            // keys past the segment's end: a hugely negative addend (the last tile of a segment only)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)          // key 32 kb + 16 ((h + j) >> 3) + ((h + j) & 7) + 8 fh is valid iff it is < the tile's key count
+          asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc"
+                       : "+v"(s[kb][h + j]) : "v"(mask_l), "n"(32 * kb + 16 * ((h + j) >> 3) + ((h + j) & 7)), "v"(-1e30f) : "vcc");
+      }
+      S.mxp[I] = max8(s[kb], h);
+    } else if constexpr (I == 4) {
+      S.mxp[0] = half_max(max3(max3(S.mxp[0], S.mxp[1], S.mxp[2]), S.mxp[3], S.mxp[3]));
+    } else if constexpr (I == 5) {
+      const float mx = S.mxp[0];
+      S.m = S.m == -1e30f ? mx : S.m;                        // the first tile sets the reference; O and l are still 0
+      if (__any((mx - S.m) * c > FAST_LOG2_RANGE)) ovf = 1;  // only a scalar is written in here
+      S.mc = S.m * c;
+    } else if constexpr (I < 22) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        constexpr int e0 = 2 * (I - 6);
+        const int e = e0 + u;
+        const int kss = e >> 3, kb = kss >> 1, r = 8 * (kss & 1) + (e & 7);
+        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -S.mc));
+      }
+      if constexpr (((2 * (I - 6) + 1) & 7) == 7) {         // the 8 values of PV k-step kss are exponentiated: pack them
+        constexpr int kss = (2 * (I - 6)) >> 3;
+        S.pf[kss] = pack8_asm(s[kss >> 1], 8 * (kss & 1));
+      }
+    } else if constexpr (I < 30) {
+      constexpr int g = I - 22;                             // elements 4 g .. 4 g + 3
+      constexpr int kss = g >> 1, kb = kss >> 1, r0 = 8 * (kss & 1) + 4 * (g & 1);
+      const float t = (s[kb][r0] + s[kb][r0 + 1]) + (s[kb][r0 + 2] + s[kb][r0 + 3]);
+      if constexpr (g < 4) S.rs[g] = t; else S.rs[g - 4] += t;
+    } else if constexpr (I == 30) {
+      S.rs[0] = half_sum((S.rs[0] + S.rs[1]) + (S.rs[2] + S.rs[3]));
+    } else {
+      S.l += S.rs[0];
+    }
+  };
+
+  // ---- the 16-fragment window (accumulator file).  Fragment f of a phase sits in fw[f]; it is read 8 gaps ahead: fragments 8-15 of a
+  // phase in its own gaps 0-7, fragments 0-7 of the NEXT phase in gaps 8-15 (slot f was consumed 8 gaps earlier in both cases).
+  bf16x8 fw[16];
+  auto read_k = [&](auto jc) __attribute__((always_inline)) -> bf16x8 {           // K fragment j = (kb, kk) of the current K slot
+    constexpr int j = decltype(jc)::value;
+    return lds_read16a(ka[j & 7], (j >> 3) * 8192);
+  };
+  auto read_v = [&](auto jc) __attribute__((always_inline)) -> bf16x8 {           // V^T fragment j = (kss, db) of the current V slot
+    constexpr int j = decltype(jc)::value;
+    return lds_read16a(va[j >> 2], (j & 3) * 4096);
+  };
+  auto keep_window = [&]() __attribute__((always_inline)) {    // see attn4_kernel: a use of every in-flight read's destination behind the wait
+    asm volatile("" ::"a"(fw[0]), "a"(fw[1]), "a"(fw[2]), "a"(fw[3]), "a"(fw[4]), "a"(fw[5]), "a"(fw[6]), "a"(fw[7]));
+    asm volatile("" ::"a"(fw[8]), "a"(fw[9]), "a"(fw[10]), "a"(fw[11]), "a"(fw[12]), "a"(fw[13]), "a"(fw[14]), "a"(fw[15]));
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  int kdelta = K_TILE_BYTES, vdelta = V_TILE_BYTES;       // what moves ka / va to the ring slot of the next A / B phase
+
+  // phase A: scores of one tile for both streams into buffer NB.  SOFT: second softmax half on buffer 1 - NB in the gaps.  NEXTA: the
+  // next MFMA phase is again an A phase (prologue), else phase B.  DMA: this wave's 4 K + 4 V^T pieces at even gaps.
+  auto phase_a = [&](auto nbc, auto softc, auto nextac, auto dmac, char* kdst, char* vdst) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nbc)::value;
+    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), NEXTA = decltype(nextac)::value != 0, DMA = decltype(dmac)::value != 0;
+    sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value, kb = f >> 3, kk = f & 7;
+      if constexpr (f < 8) fw[f + 8] = read_k(std::integral_constant<int, (f < 8 ? f + 8 : 0)>{});
+      else if constexpr (NEXTA) {
+        ka[f - 8] += kdelta;
+        fw[f - 8] = read_k(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
+      } else fw[f - 8] = read_v(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
+      lds_wait<8>();
+      if constexpr (!(DIAG & 2)) {
+        if constexpr (kk == 0) mfma_sa_first(sc[NB][0][kb], fw[f], qf[0][kk]); else mfma_sa_next(sc[NB][0][kb], fw[f], qf[0][kk]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SOFT) soft_slot(I0{}, std::integral_constant<int, 1 - NB>{}, std::integral_constant<int, 16 + f>{});
+      if constexpr (DMA && (f & 1) == 0) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(DIAG & 2)) {
+        if constexpr (kk == 0) mfma_sa_first(sc[NB][1][kb], fw[f], qf[1][kk]); else mfma_sa_next(sc[NB][1][kb], fw[f], qf[1][kk]);
+      } else asm volatile("" ::"a"(fw[f]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SOFT) soft_slot(I1{}, std::integral_constant<int, 1 - NB>{}, std::integral_constant<int, 16 + f>{});
+      if constexpr (!NEXTA && f >= 8) ka[f - 8] += kdelta;
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // phase B: O += V^T P for both streams; SOFT: first softmax half on buffer SB in the gaps.  The next phase is an A phase.
+  auto phase_b = [&](auto sbc, auto softc) __attribute__((always_inline)) {
+    constexpr int SB = decltype(sbc)::value;
+    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1);
+    sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value, kss = f >> 2, db = f & 3;
+      if constexpr (f < 8) fw[f + 8] = read_v(std::integral_constant<int, (f < 8 ? f + 8 : 0)>{});
+      else fw[f - 8] = read_k(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
+      lds_wait<8>();
+      if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], st[0].pf[kss]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SOFT) soft_slot(I0{}, sbc, fc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], st[1].pf[kss]); else asm volatile("" ::"a"(fw[f]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SOFT) soft_slot(I1{}, sbc, fc);
+      if constexpr (f >= 8 && f < 12) va[f - 8] += vdelta;        // every read of this V slot is issued (gaps 0-7): on to the next one
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  if (total_tiles > 0) {
+    {
+      int s0 = 0;
+      while (s0 < 3 && NK(s0) == 0) ++s0;
+      enter(s0);
+    }
+    x2 = lag_of(); v_offsets();
+    const int valid0 = x2.valid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i, kring + wid * 4096);                          // K(0) -> K slot 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v(i, vring + wid * 4096);                          // V(0) -> V slot 0
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i, kring + K_TILE_BYTES + wid * 4096);           // K(1) -> K slot 1 (past the end: the last tile again)
+    x2 = lag_of(); v_offsets();
+    valid1 = x2.valid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v(i, vring + V_TILE_BYTES + wid * 4096);           // V(1) -> V slot 1
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i, kring + 2 * K_TILE_BYTES + wid * 4096);       // K(2) -> K slot 2
+    x2 = lag_of(); v_offsets();                                                         // x2 = tile 2
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i, kring + 3 * K_TILE_BYTES + wid * 4096);       // K(3) -> K slot 3
+    x3 = lag_of();                                                                      // x3 = tile 3
+    advance();                                                                          // w  = tile 4
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- prologue: A(0) alone into buffer 0 (reads ahead into A(1): K slot 1), then the first softmax half of tile 0 alone
+    if (wave_on) {
+      sfor<0, 8>([&](auto jc) __attribute__((always_inline)) { fw[decltype(jc)::value] = read_k(jc); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      kdelta = K_TILE_BYTES;
+      phase_a(I0{}, I0{}, I1{}, I0{}, kring, vring);
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> vector ALU: hipcc pads nothing behind an asm MFMA
+      ragged = valid0 < KT;
+      mask_l = valid0 - 8 * fh;
+      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { soft_slot(I0{}, I0{}, ic); soft_slot(I1{}, I0{}, ic); });
+    }
+    int kst = 0, vst = 0;    // t % 4, t % 3: K(t + 4) is staged into K slot kst, V^T(t + 2) into V slot (vst + 2) % 3
+    // step t (P = t & 1): A(t+1) -> buffer 1 - P from the K slot ka points at | second half(t) on buffer P;  B(t) from the V slot va points at | first half(t+1)
+    auto step = [&](auto pc) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value;
+      // this wave's pieces of the tiles staged two steps ago (K(t+2), V(t)) have landed - last step's eight stay in flight - ...
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // ... and everyone's; every wave finished step t - 1
+      asm volatile("" ::: "memory");
+      char* kdst = kring + kst * K_TILE_BYTES + wid * 4096;
+      char* vdst = vring + (vst == 0 ? 2 : vst - 1) * V_TILE_BYTES + wid * 4096;
+      if (wave_on) {
+        ragged = valid1 < KT;
+        mask_l = valid1 - 8 * fh;
+        kdelta = kst == 2 ? -(K5_SLOTS - 1) * K_TILE_BYTES : K_TILE_BYTES;
+        vdelta = vst == 2 ? -(V5_SLOTS - 1) * V_TILE_BYTES : V_TILE_BYTES;
+        phase_a(std::integral_constant<int, 1 - P>{}, I1{}, I0{}, I1{}, kdst, vdst);
+        phase_b(std::integral_constant<int, 1 - P>{}, I1{});
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_k(i, kdst);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_v(i, vdst);
+      }
+      valid1 = x2.valid; x2 = x3; x3 = lag_of(); v_offsets(); advance();
+      kst = kst == 3 ? 0 : kst + 1;
+      vst = vst == 2 ? 0 : vst + 1;
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < total_tiles; t += 2) { step(I0{}); step(I1{}); }
+    if (t < total_tiles) step(I0{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA / look-ahead read may be in flight when the workgroup ends
+    if (wave_on) keep_window();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last PV MFMAs -> the epilogue's accumulator reads
+  }
+  // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
+  if (lane == 0) wflags[wid] = ovf;
+  __syncthreads();
+  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
+  if (!wave_on) return;
+
+  // ---- epilogue: lane holds O[q = 32 qb + fr][32 d + 8 g + 4 fh + 0..3]; gate values requested as one batch per query stream
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = qbase + wid * 64 + qb * 32 + fr;
+    if (q >= p.S) continue;
+    uint2 gq[4][4];
+    const bf16_t* gp = p.G ? p.G + (long)row * p.g_row_stride + (long)q * p.g_ld + head * HD + 4 * fh : nullptr;
+    if (gp) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[d][g] = *(const uint2*)(gp + 32 * d + 8 * g);
+    }
+    const float inv_l = 1.0f / st[qb].l;
+    bf16_t* op = p.O + (long)row * p.o_row_stride + (long)q * p.o_ld + head * HD + 4 * fh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[qb][d][4 * g + i] * inv_l));
+        if (gp) {
+          float gv[4];
+          Vec4<bf16_t>::unpack(gq[d][g], gv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
+        }
+        *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
+      }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
@@ -878,28 +1282,26 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.S + QT - 1) / QT, a.H, a.rows);
   bool bias = false;
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
-  // ECHO_ATTN4=1 selects attn4_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention.  Measured (round 2, DESIGN.md
-  // §3.2): it ties attn_kernel at the bench shape (620 vs 627 TFLOP/s at 24 rows) and loses below 8 rows, so attn_kernel stays the default.
-  static const bool use4 = getenv("ECHO_ATTN4") && atoi(getenv("ECHO_ATTN4")) != 0;
-  if (!a.causal && !bias && !a.prof && use4 && a.redo) {
-    // the joint attention of the sampler steps (and the text encoder): 4 waves x 64 queries, one wave per SIMD, then attn_kernel
-    // for the (normally zero) workgroups whose scores left the fast kernel's range; both on the caller's stream
-    static std::atomic<unsigned long long> prep4[8];
+  // ECHO_ATTN=4 / 5 select attn4_kernel / attn5_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention, then attn_kernel
+  // for the (normally zero) workgroups whose scores left the fast kernels' range; both launches on the caller's stream.
+  static const int variant = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : (getenv("ECHO_ATTN4") && atoi(getenv("ECHO_ATTN4")) ? 4 : 0);
+  if (!a.causal && !bias && !a.prof && (variant == 4 || variant == 5) && a.redo) {
+    static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
-    const int di = diag == 1 ? 1 : diag == 2 ? 2 : diag == 3 ? 3 : diag == 7 ? 4 : diag == 48 ? 5 : diag == 112 ? 6 : diag == 16 ? 7 : 0;
-    const void* k4[8] = {(const void*)attn4_kernel<0>, (const void*)attn4_kernel<1>, (const void*)attn4_kernel<2>, (const void*)attn4_kernel<3>,
-                         (const void*)attn4_kernel<7>, (const void*)attn4_kernel<48>, (const void*)attn4_kernel<112>, (const void*)attn4_kernel<16>};
-    if (hipError_t e = ensure_dyn_lds(k4[di], SMEM4, prep4[di]); e != hipSuccess) return e;
     const dim3 g4((a.S + 255) / 256, a.H, a.rows);
-    switch (di) {
-      case 1: hipLaunchKernelGGL(attn4_kernel<1>, g4, dim3(256), SMEM4, st, a); break;
-      case 2: hipLaunchKernelGGL(attn4_kernel<2>, g4, dim3(256), SMEM4, st, a); break;
-      case 3: hipLaunchKernelGGL(attn4_kernel<3>, g4, dim3(256), SMEM4, st, a); break;
-      case 4: hipLaunchKernelGGL(attn4_kernel<7>, g4, dim3(256), SMEM4, st, a); break;
-      case 5: hipLaunchKernelGGL(attn4_kernel<48>, g4, dim3(256), SMEM4, st, a); break;
-      case 6: hipLaunchKernelGGL(attn4_kernel<112>, g4, dim3(256), SMEM4, st, a); break;
-      case 7: hipLaunchKernelGGL(attn4_kernel<16>, g4, dim3(256), SMEM4, st, a); break;
-      default: hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
+    if (variant == 4) {
+      if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
+      hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
+    } else {
+      const int di = diag == 1 ? 2 : diag == 2 ? 3 : diag == 3 ? 4 : 1;
+      const void* k5[5] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<1>, (const void*)attn5_kernel<2>, (const void*)attn5_kernel<3>};
+      if (hipError_t e = ensure_dyn_lds(k5[di], SMEM5, prep4[di]); e != hipSuccess) return e;
+      switch (di) {
+        case 2: hipLaunchKernelGGL(attn5_kernel<1>, g4, dim3(256), SMEM5, st, a); break;
+        case 3: hipLaunchKernelGGL(attn5_kernel<2>, g4, dim3(256), SMEM5, st, a); break;
+        case 4: hipLaunchKernelGGL(attn5_kernel<3>, g4, dim3(256), SMEM5, st, a); break;
+        default: hipLaunchKernelGGL(attn5_kernel<0>, g4, dim3(256), SMEM5, st, a);
+      }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     AttnArgs b = a;

@@ -159,7 +159,7 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
     branch): spike 2 stays inside the fast kernel's range (P up to 2^32 against the first tile's reference), spike 20 leaves it, so
     the workgroup must be flagged and redone by attn_kernel with per-tile rescaling - that query's output is then one value row.
     The default build runs attn_kernel (deferred rescale: the spikes force its rescale branch); tests/test_gpu_kernels.py::
-    test_attention_fast_kernel_variant repeats the spike cases in a child process with ECHO_ATTN4=1."""
+    test_attention_fast_kernel_variant repeats the spike cases in child processes with ECHO_ATTN=4 and 5."""
     R, H = 3, 2
     q = rnd(R, S, H, 128, dtype=torch.bfloat16)
     k_self, v_self = rnd(R, S, H, 128, dtype=torch.bfloat16, seed=1), rnd(R, S, H, 128, dtype=torch.bfloat16, seed=2)
@@ -214,15 +214,17 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
     assert float(err.mean()) < 2e-3, float(err.mean())
 
 
-def test_attention_fast_kernel_variant():
-    """attn4_kernel (ECHO_ATTN4=1, read once per process): the joint-segment cases incl. the range-fallback spikes, in a child process."""
+@pytest.mark.parametrize("variant", ["4", "5"])
+def test_attention_fast_kernel_variant(variant):
+    """attn4_kernel / attn5_kernel (ECHO_ATTN=4 / 5, read once per process): the joint-segment cases incl. the range-fallback spikes and
+    the tile counts of every remainder class of their unrolled loops, in a child process."""
     import os, subprocess, sys
-    if os.environ.get("ECHO_ATTN4") == "1":
-        pytest.skip("already the variant run")
-    env = dict(os.environ, ECHO_ATTN4="1")
+    if os.environ.get("ECHO_ATTN"):
+        pytest.skip("already a variant run")
+    env = dict(os.environ, ECHO_ATTN=variant)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "joint_segments or deterministic_at_full_size"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+                        "joint_segments or deterministic_at_full_size or attention_tile_count_classes"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -600,6 +602,58 @@ def test_attention_is_deterministic_at_full_size(R):
     ref = (ref.bfloat16().float() * torch.sigmoid(qkvg[:S, 3 * D:3 * D + 128].float()).bfloat16().float())
     err = (outs[0][:S, :128].float() - ref).abs()
     assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3
+
+
+@pytest.mark.parametrize("Lt,Ls", [(436, 640), (372, 640), (308, 640), (500, 600), (64, 0), (1, 0), (0, 0)])
+def test_attention_tile_count_classes(Lt, Ls):
+    """Every row, head and query against fp32 at S = 640 for key-tile counts in every remainder class of the kernels' unrolled loops
+    (27 / 20 / 17, 26 / 20 / 16, 25 / 20 / 15, 28 / 20 / 18, 11 / 10, 10 tiles per row) incl. ragged last tiles and one-key segments;
+    three launches bit-identical (a value placed in the destination of an in-flight LDS read showed up only at total_tiles % 3 == 2)."""
+    R, S, H = 3, 640, 4
+    D = H * 128
+    qkvg = rnd(R * S + 256, 4 * D, dtype=torch.bfloat16, scale=0.5)
+    pS, pT, pSp = (S + 63) // 64 * 64, max(64, (Lt + 63) // 64 * 64), max(64, (Ls + 63) // 64 * 64)
+    vt_self = rnd(R, H, 128, pS, dtype=torch.bfloat16, seed=1)
+    kt, vt_t = rnd(Lt + 128, 4 * D, dtype=torch.bfloat16, seed=2), rnd(1, H, 128, pT, dtype=torch.bfloat16, seed=3)
+    ksp, vt_s = rnd(Ls + 128, 4 * D, dtype=torch.bfloat16, seed=4), rnd(1, H, 128, pSp, dtype=torch.bfloat16, seed=5)
+    rows = [[S] * R, [Lt, 0, Lt], [Ls, Ls, 0]]
+    nk = torch.tensor(rows, dtype=torch.int32, device=DEV)
+    outs = []
+    for _ in range(3):
+        out = torch.zeros((R * S, D), dtype=torch.bfloat16, device=DEV)
+        d = L.EchoAttnDesc()
+        d.Q, d.q_ld, d.q_row_stride = qkvg.data_ptr(), 4 * D, S * 4 * D
+        d.O, d.o_ld, d.o_row_stride = out.data_ptr(), D, S * D
+        d.G, d.g_ld, d.g_row_stride = qkvg.data_ptr() + 3 * D * 2, 4 * D, S * 4 * D
+        d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 3, 0, 1 / math.sqrt(128)
+        for i, (kp, kld, krs, vt, pitch, shared) in enumerate(((qkvg.data_ptr() + D * 2, 4 * D, S * 4 * D, vt_self, pS, False),
+                                                               (kt.data_ptr(), 4 * D, 0, vt_t, pT, True),
+                                                               (ksp.data_ptr(), 4 * D, 0, vt_s, pSp, True))):
+            sg = d.seg[i]
+            sg.K, sg.k_ld, sg.k_head_stride, sg.k_row_stride = kp, kld, 128, krs
+            sg.Vt, sg.vt_ld, sg.vt_head_stride = vt.data_ptr(), pitch, 128 * pitch
+            sg.vt_row_stride = 0 if shared else H * 128 * pitch
+            sg.nkeys = nk[i].data_ptr()
+            sg.kv_mod = 1 if shared else 0
+        L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for r in range(R):
+        q = qkvg[r * S:(r + 1) * S, :D].float().view(S, H, 128).transpose(0, 1)
+        ks = [qkvg[r * S:(r + 1) * S, D:2 * D].float().view(S, H, 128).transpose(0, 1)]
+        vs = [vt_self[r, :, :, :S].float().transpose(1, 2)]
+        if rows[1][r]:
+            ks.append(kt[:Lt, :D].float().view(Lt, H, 128).transpose(0, 1)); vs.append(vt_t[0, :, :, :Lt].float().transpose(1, 2))
+        if rows[2][r]:
+            ks.append(ksp[:Ls, :D].float().view(Ls, H, 128).transpose(0, 1)); vs.append(vt_s[0, :, :, :Ls].float().transpose(1, 2))
+        k, v = torch.cat(ks, 1), torch.cat(vs, 1)
+        ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(128), -1) @ v
+        gate = torch.sigmoid(qkvg[r * S:(r + 1) * S, 3 * D:].float()).bfloat16().float().view(S, H, 128).transpose(0, 1)
+        ref = ref.bfloat16().float() * gate
+        got = outs[0][r * S:(r + 1) * S].float().view(S, H, 128).transpose(0, 1)
+        err = (got - ref).abs()
+        assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3, (r, float(err.max()), float(err.mean()))
 
 
 def test_plain_c_caller_runs_through_the_abi(tmp_path):

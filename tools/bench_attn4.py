@@ -1,5 +1,5 @@
 """Joint-attention micro-benchmark at the sampler's shapes (run on the GPU box): R rows x 16 heads x 640 queries against self 640 |
-text 436 | speaker 640 keys with the CFG rows' segment switches.  ECHO_ATTN4=1 times attn4_kernel (4 waves x 64 queries) instead of the default 8-wave attn_kernel;
+text 436 | speaker 640 keys with the CFG rows' segment switches.  ECHO_ATTN=4 / 5 time attn4_kernel / attn5_kernel (4 waves x 64 queries) instead of the 8-wave attn_kernel;
 both variants are checked against each other by tests/test_gpu_kernels.py, this tool only times."""
 import ctypes as C, math, os, sys
 import torch
@@ -51,7 +51,7 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
     ms = sorted(ts)[1]
     keys = sum(sum(r[i] for r in rows) for i in range(R))
     fl = 4.0 * S * keys * D
-    print(f"attn {'v4' if os.environ.get('ECHO_ATTN4') == '1' else 'v1'} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
+    print(f"attn {'v' + os.environ.get('ECHO_ATTN', '1')} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
 
 
 if __name__ == "__main__":

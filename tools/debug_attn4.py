@@ -1,4 +1,4 @@
-"""Where does attn4_kernel (ECHO_ATTN4=1) differ from an fp32 reference?  Per row / head / 64-query block error maxima at the C2 shape
+"""Where does attn4_kernel / attn5_kernel (ECHO_ATTN=4 / 5) differ from an fp32 reference?  Per row / head / 64-query block error maxima at the C2 shape
 with the CFG rows' empty segments (debug aid, run on the GPU box)."""
 import ctypes as C, math, os, sys
 import torch
