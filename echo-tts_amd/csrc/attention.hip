@@ -867,11 +867,15 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
 // fragment: one ds_read_b128 feeds two MFMAs (stream 0 and stream 1).  attn4_kernel (and attn_kernel) read one 1 KiB fragment per
 // MFMA: 4 waves x 1 KiB / 32 cycles = 128 B/clk/CU, the whole LDS bandwidth - its "no MFMA, no softmax" ablation build still takes
 // 120-147 us of the 250.  Here it is 64 B/clk.
-//   step t:   A(t+1): S0,S1(t+1) = K(t+1) Q0^T, K(t+1) Q1^T   (16 K fragments, 32 MFMAs)  | second half of softmax(t), both streams
-//             B(t):   O0,O1 += V^T(t) P0,P1(t)                 (16 V fragments, 32 MFMAs)  | first half of softmax(t+1)
-// Scores are double-buffered in arch VGPRs (asm MFMAs in the VGPR form: 2 x 64 registers), P is packed in place of the consumed
-// scores' successors (32 registers), O (128), Q (64) and a 16-fragment window of K / V^T fragments (64, written by ds_read directly)
-// fill the accumulator file.  Softmax slots, fixed reference + range fallback, masking and the tile walk are attn4_kernel's.
+//   step t:   A(t+1): S0,S1(t+1) = K(t+1) Q0^T, K(t+1) Q1^T   (16 K fragments, 32 MFMAs)  | late(t), both streams
+//             B(t):   O0,O1 += V^T(t) P0,P1(t)                 (16 V fragments, 32 MFMAs)  | early(t+1)
+// Scores are double-buffered in arch VGPRs (asm MFMAs in the VGPR form: 2 x 64 registers), P is packed into 32 more; O (128), Q (64)
+// and a 16-fragment window of K / V^T fragments (64, written by ds_read directly) fill the accumulator file.
+// Softmax WITHOUT a reference point: Q is pre-multiplied by scale * log2(e) (bf16), so the MFMA result is the exp2 argument and
+// P = exp2(S) - no row maximum, no subtraction, no rescale: per element one v_exp_f32, one add (row sum) and half a v_cvt_pk.  fp32 and
+// bf16 share the exponent range, so this is exact as long as the row sum l stays inside [2^-64, 2^64] (RMS-normalised q, k: |S| < ~20);
+// a workgroup whose l leaves that range (or is not finite) reports it in `redo` and attn_kernel redoes it with the online softmax.
+//   early(t): exp2 + row sum of the kb = 0 half of tile t (rides B(t-1));  late(t): the kb = 1 half, the packing of P, l (rides A(t+1)).
 // Rings: K four tiles, V^T three: step t stages K(t+4) and V^T(t+2), i.e. every tile two steps before its first reader (the look-ahead
 // reads at the end of step t already touch K(t+2)), so the per-step wait is vmcnt(8) - the previous step's eight pieces stay in flight.
 // Ring slots are not literals (the loop is unrolled by two, for the score buffers): the eight K and four V^T read addresses move by
@@ -908,15 +912,18 @@ __device__ __forceinline__ bf16x8 pack8_asm(const f32x16& s, int base) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Soft5 {           // softmax state of one query stream (the scores live in sc[buf][q][kb])
-  bf16x8 pf[4];          // P^T as the B operand of the four PV k-steps
-  float m, l, mc;
-  float mxp[4], rs[4];
+  u32x4 pf[4];           // P^T (bf16 pairs) as the B operand of the four PV k-steps
+  float l, rs;           // denominator; row sum of the tile in flight
 };
 
-// DIAG bits (timing experiments only, wrong results): 1 = no softmax VALU work, 2 = no MFMAs
+// DIAG bits (timing experiments): 1 = no softmax VALU work, 2 = no MFMAs, 8 = linear (trivially conflict-free) fragment addresses (all three:
+// wrong results), 16 = no LDS-DMA in the loop, 32 = no LDS reads, 4 = s_memtime stamps per phase into p.prof
 template <int DIAG>
 __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t_end = 0;
+  if constexpr (DIAG & 4) k_t0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [4][16 KiB] | V ring [3][16 KiB] | 4 range flags
   constexpr int QW = 256;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -936,7 +943,14 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     const int qc = qi < p.S ? qi : p.S - 1;
     const bf16_t* qp = p.Q + (long)row * p.q_row_stride + (long)qc * p.q_ld + head * HD + 8 * fh;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + 16 * kk);
+    for (int kk = 0; kk < 8; ++kk) {
+      const bf16x8 raw = *(const bf16x8*)(qp + 16 * kk);
+      f32x8 v = __builtin_convertvector(__builtin_bit_cast(hbf16x8, raw), f32x8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.scale * 1.4426950408889634f;
+      qf[qb][kk] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hbf16x8));
+      asm volatile("" : "+a"(qf[qb][kk]));          // from here on an accumulator-file value: no per-use copies
+    }
   }
 
   int nkraw[4];
@@ -1015,13 +1029,12 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   {
     const unsigned kbase = (unsigned)(unsigned long)(lptr_t)kring, vbase = (unsigned)(unsigned long)(lptr_t)vring;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ka[kk] = kbase + pi_row * 256 + (((2 * kk + fh) ^ sw_k) << 4);
+    for (int kk = 0; kk < 8; ++kk) ka[kk] = (DIAG & 8) ? kbase + lane * 16 + kk * 1024 : kbase + pi_row * 256 + (((2 * kk + fh) ^ sw_k) << 4);
 #pragma unroll
-    for (int kss = 0; kss < 4; ++kss) va[kss] = vbase + fr * 128 + (((2 * kss + fh) ^ sw_v) << 4);
+    for (int kss = 0; kss < 4; ++kss) va[kss] = (DIAG & 8) ? vbase + lane * 16 + kss * 1024 : vbase + fr * 128 + (((2 * kss + fh) ^ sw_v) << 4);
   }
-  const float c = p.scale * 1.4426950408889634f;
   f32x16 o[2][4];            // accumulator file (asm "+a")
-  f32x16 sc[2][2][2];        // [buffer][stream][kb] scores / P of a tile: arch VGPRs (asm "=&v" / "+v")
+  f32x16 sc[2][2][2];        // [buffer][stream][kb] exp2 arguments / P of a tile: arch VGPRs (asm "=&v" / "+v")
   Soft5 st[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -1029,68 +1042,67 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
-    st[qb].m = -1e30f; st[qb].l = 0.0f; st[qb].mc = -1e30f * c;
+    st[qb].l = 0.0f; st[qb].rs = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st[qb].pf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; st[qb].mxp[i] = 0.f; st[qb].rs[i] = 0.f; }
+    for (int i = 0; i < 4; ++i) st[qb].pf[i] = u32x4{0, 0, 0, 0};
   }
-  int ovf = 0;             // a score left the fixed reference's range (wave-uniform)
-  bool ragged = false;     // the tile whose first softmax half runs has fewer than KT valid keys (wave-uniform)
+  bool ragged = false;     // the tile whose early half runs next has fewer than KT valid keys (wave-uniform)
   int mask_l = 0;          // its valid keys - 8 fh
 
-  // ---- softmax of stream q on score buffer b, cut into 32 slots (attn4_kernel's): 0-15 = first half, 16-31 = second half
-  auto soft_slot = [&](auto qc_, auto bc_, auto ic_) __attribute__((always_inline)) {
-    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, I = decltype(ic_)::value;
-    Soft5& S = st[q];
-    f32x16 (&s)[2] = sc[b][q];
-    if constexpr (I < 4) {
-      constexpr int kb = I >> 1, h = 8 * (I & 1);
-      if (__builtin_expect(ragged, 0)) {            // keys past the segment's end: a hugely negative addend (the last tile of a segment only)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)          // key 32 kb + 16 ((h + j) >> 3) + ((h + j) & 7) + 8 fh is valid iff it is < the tile's key count
-          asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc"
-                       : "+v"(s[kb][h + j]) : "v"(mask_l), "n"(32 * kb + 16 * ((h + j) >> 3) + ((h + j) & 7)), "v"(-1e30f) : "vcc");
-      }
-      S.mxp[I] = max8(s[kb], h);
-    } else if constexpr (I == 4) {
-      S.mxp[0] = half_max(max3(max3(S.mxp[0], S.mxp[1], S.mxp[2]), S.mxp[3], S.mxp[3]));
-    } else if constexpr (I == 5) {
-      const float mx = S.mxp[0];
-      S.m = S.m == -1e30f ? mx : S.m;                        // the first tile sets the reference; O and l are still 0
-      if (__any((mx - S.m) * c > FAST_LOG2_RANGE)) ovf = 1;  // only a scalar is written in here
-      S.mc = S.m * c;
-    } else if constexpr (I < 22) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        constexpr int e0 = 2 * (I - 6);
-        const int e = e0 + u;
-        const int kss = e >> 3, kb = kss >> 1, r = 8 * (kss & 1) + (e & 7);
-        s[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -S.mc));
-      }
-      if constexpr (((2 * (I - 6) + 1) & 7) == 7) {         // the 8 values of PV k-step kss are exponentiated: pack them
-        constexpr int kss = (2 * (I - 6)) >> 3;
-        S.pf[kss] = pack8_asm(s[kss >> 1], 8 * (kss & 1));
-      }
-    } else if constexpr (I < 30) {
-      constexpr int g = I - 22;                             // elements 4 g .. 4 g + 3
-      constexpr int kss = g >> 1, kb = kss >> 1, r0 = 8 * (kss & 1) + 4 * (g & 1);
-      const float t = (s[kb][r0] + s[kb][r0 + 1]) + (s[kb][r0 + 2] + s[kb][r0 + 3]);
-      if constexpr (g < 4) S.rs[g] = t; else S.rs[g - 4] += t;
-    } else if constexpr (I == 30) {
-      S.rs[0] = half_sum((S.rs[0] + S.rs[1]) + (S.rs[2] + S.rs[3]));
-    } else {
-      S.l += S.rs[0];
+  // keys past a segment's end (the last tile of a segment only): exp2 argument -1e30.  Register r of sc[..][kb] = key 32 kb + 16 (r >> 3)
+  // + 8 fh + (r & 7).  Runs in front of early(): directly behind the tile's last score MFMA, hence the wait states.
+  auto mask_tile = [&](auto bc_) __attribute__((always_inline)) {
+    constexpr int b = decltype(bc_)::value;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const float gone = -1e30f;
+    sfor<0, 64>([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value, q = e >> 5, kb = (e >> 4) & 1, r = e & 15;
+      float x = sc[b][q][kb][r];
+      asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(x) : "v"(mask_l), "n"(32 * kb + 16 * (r >> 3) + (r & 7)), "v"(gone) : "vcc");
+      sc[b][q][kb][r] = x;
+    });
+  };
+  // early(): element g of the kb = 0 half: P = exp2(S), row sum.  late(): element g of the kb = 1 half, one v_cvt_pk of finished pairs
+  // (kb 0 pairs in gaps 0-7, kb 1 pair g - 8 in gaps 8-15), and the denominator in gap 15.
+  auto early = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
+    const float x = __builtin_amdgcn_exp2f(sc[b][q][0][g]);       // its add comes one element later: no wait state behind the v_exp
+    sc[b][q][0][g] = x;
+    if constexpr (g == 1) st[q].rs = sc[b][q][0][0];
+    else if constexpr (g > 1) st[q].rs += sc[b][q][0][g - 1];
+  };
+  auto cvt_pair = [&](auto qc_, auto bc_, auto kbc_, auto jc_) __attribute__((always_inline)) {      // pair j (elements 2 j, 2 j + 1) of half kb
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, kb = decltype(kbc_)::value, j = decltype(jc_)::value;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {sc[b][q][kb][2 * j], sc[b][q][kb][2 * j + 1]};
+    st[q].pf[2 * kb + (j >> 2)][j & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));   // one v_cvt_pk_bf16_f32
+  };
+  auto late = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
+    const float x = __builtin_amdgcn_exp2f(sc[b][q][1][g]);
+    sc[b][q][1][g] = x;
+    if constexpr (g == 0) st[q].rs += sc[b][q][0][15]; else st[q].rs += sc[b][q][1][g - 1];
+    if constexpr (g < 8) cvt_pair(qc_, bc_, std::integral_constant<int, 0>{}, gc_);
+    else cvt_pair(qc_, bc_, std::integral_constant<int, 1>{}, std::integral_constant<int, (g >= 8 ? g - 8 : 0)>{});
+    if constexpr (g == 15) {
+      cvt_pair(qc_, bc_, std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{});
+      st[q].l += half_sum(st[q].rs + x);
     }
   };
 
-  // ---- the 16-fragment window (accumulator file).  Fragment f of a phase sits in fw[f]; it is read 8 gaps ahead: fragments 8-15 of a
-  // phase in its own gaps 0-7, fragments 0-7 of the NEXT phase in gaps 8-15 (slot f was consumed 8 gaps earlier in both cases).
+  // ---- the 16-fragment window (accumulator file).  Fragment f of a phase sits in fw[f]; it is read LA gaps ahead: fragments LA..15 of a
+  // phase in its own gaps 0..15-LA, fragments 0..LA-1 of the NEXT phase in gaps 16-LA..15 (slot f was consumed 16 - LA gaps earlier).
   bf16x8 fw[16];
+  constexpr int LA = 8;      // look-ahead of the fragment reads, in fragments (= gap pairs); 12 makes hipcc spill Q fragments to scratch
   auto read_k = [&](auto jc) __attribute__((always_inline)) -> bf16x8 {           // K fragment j = (kb, kk) of the current K slot
     constexpr int j = decltype(jc)::value;
+    if constexpr (DIAG & 32) { bf16x8 z; asm volatile("" : "=a"(z)); return z; }
     return lds_read16a(ka[j & 7], (j >> 3) * 8192);
   };
   auto read_v = [&](auto jc) __attribute__((always_inline)) -> bf16x8 {           // V^T fragment j = (kss, db) of the current V slot
     constexpr int j = decltype(jc)::value;
+    if constexpr (DIAG & 32) { bf16x8 z; asm volatile("" : "=a"(z)); return z; }
     return lds_read16a(va[j >> 2], (j & 3) * 4096);
   };
   auto keep_window = [&]() __attribute__((always_inline)) {    // see attn4_kernel: a use of every in-flight read's destination behind the wait
@@ -1108,25 +1120,26 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), NEXTA = decltype(nextac)::value != 0, DMA = decltype(dmac)::value != 0;
     sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kb = f >> 3, kk = f & 7;
-      if constexpr (f < 8) fw[f + 8] = read_k(std::integral_constant<int, (f < 8 ? f + 8 : 0)>{});
+      constexpr int j = f + LA, nj = j >= 16 ? j - 16 : 0;
+      if constexpr (j < 16) fw[j] = read_k(std::integral_constant<int, (j < 16 ? j : 0)>{});
       else if constexpr (NEXTA) {
-        ka[f - 8] += kdelta;
-        fw[f - 8] = read_k(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
-      } else fw[f - 8] = read_v(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
-      lds_wait<8>();
+        if constexpr (nj < 8) ka[nj] += kdelta;
+        fw[nj] = read_k(std::integral_constant<int, nj>{});
+      } else fw[nj] = read_v(std::integral_constant<int, nj>{});
+      lds_wait<LA>();
       if constexpr (!(DIAG & 2)) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][0][kb], fw[f], qf[0][kk]); else mfma_sa_next(sc[NB][0][kb], fw[f], qf[0][kk]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) soft_slot(I0{}, std::integral_constant<int, 1 - NB>{}, std::integral_constant<int, 16 + f>{});
-      if constexpr (DMA && (f & 1) == 0) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }
+      if constexpr (SOFT) late(I0{}, std::integral_constant<int, 1 - NB>{}, fc);
+      if constexpr (DMA && (f & 1) == 0 && !(DIAG & 16)) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(DIAG & 2)) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][1][kb], fw[f], qf[1][kk]); else mfma_sa_next(sc[NB][1][kb], fw[f], qf[1][kk]);
       } else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) soft_slot(I1{}, std::integral_constant<int, 1 - NB>{}, std::integral_constant<int, 16 + f>{});
-      if constexpr (!NEXTA && f >= 8) ka[f - 8] += kdelta;
+      if constexpr (SOFT) late(I1{}, std::integral_constant<int, 1 - NB>{}, fc);
+      if constexpr (!NEXTA && f >= 16 - LA && f < 24 - LA) ka[f - (16 - LA)] += kdelta;      // every read of this K slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -1134,19 +1147,21 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   auto phase_b = [&](auto sbc, auto softc) __attribute__((always_inline)) {
     constexpr int SB = decltype(sbc)::value;
     constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1);
+    if constexpr (SOFT) { if (__builtin_expect(ragged, 0)) mask_tile(sbc); }
     sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kss = f >> 2, db = f & 3;
-      if constexpr (f < 8) fw[f + 8] = read_v(std::integral_constant<int, (f < 8 ? f + 8 : 0)>{});
-      else fw[f - 8] = read_k(std::integral_constant<int, (f >= 8 ? f - 8 : 0)>{});
-      lds_wait<8>();
-      if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], st[0].pf[kss]);
+      constexpr int j = f + LA, nj = j >= 16 ? j - 16 : 0;
+      if constexpr (j < 16) fw[j] = read_v(std::integral_constant<int, (j < 16 ? j : 0)>{});
+      else fw[nj] = read_k(std::integral_constant<int, nj>{});
+      lds_wait<LA>();
+      if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) soft_slot(I0{}, sbc, fc);
+      if constexpr (SOFT) early(I0{}, sbc, fc);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], st[1].pf[kss]); else asm volatile("" ::"a"(fw[f]));
+      if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) soft_slot(I1{}, sbc, fc);
-      if constexpr (f >= 8 && f < 12) va[f - 8] += vdelta;        // every read of this V slot is issued (gaps 0-7): on to the next one
+      if constexpr (SOFT) early(I1{}, sbc, fc);
+      if constexpr (f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -1179,27 +1194,33 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     for (int i = 0; i < 4; ++i) dma_k(i, kring + 3 * K_TILE_BYTES + wid * 4096);       // K(3) -> K slot 3
     x3 = lag_of();                                                                      // x3 = tile 3
     advance();                                                                          // w  = tile 4
+    if constexpr (DIAG & 4) pt[4] = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- prologue: A(0) alone into buffer 0 (reads ahead into A(1): K slot 1), then the first softmax half of tile 0 alone
+    if constexpr (DIAG & 4) k_r0 = stamp() - k_t0;     // (reused) setup + first tiles landed
+    // ---- prologue: A(0) alone into buffer 0 (reads ahead into A(1): K slot 1), then early(0) alone
     if (wave_on) {
-      sfor<0, 8>([&](auto jc) __attribute__((always_inline)) { fw[decltype(jc)::value] = read_k(jc); });
+      sfor<0, LA>([&](auto jc) __attribute__((always_inline)) { fw[decltype(jc)::value] = read_k(jc); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       kdelta = K_TILE_BYTES;
       phase_a(I0{}, I0{}, I1{}, I0{}, kring, vring);
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> vector ALU: hipcc pads nothing behind an asm MFMA
-      ragged = valid0 < KT;
       mask_l = valid0 - 8 * fh;
-      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { soft_slot(I0{}, I0{}, ic); soft_slot(I1{}, I0{}, ic); });
+      if (valid0 < KT) mask_tile(I0{});
+      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early(I0{}, I0{}, ic); early(I1{}, I0{}, ic); });
     }
+    if constexpr (DIAG & 4) pt[5] = stamp() - k_t0;      // prologue: setup, first tiles landed, A(0), early(0)
     int kst = 0, vst = 0;    // t % 4, t % 3: K(t + 4) is staged into K slot kst, V^T(t + 2) into V slot (vst + 2) % 3
     // step t (P = t & 1): A(t+1) -> buffer 1 - P from the K slot ka points at | second half(t) on buffer P;  B(t) from the V slot va points at | first half(t+1)
     auto step = [&](auto pc) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
+      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if constexpr (DIAG & 4) { s0 = stamp(); if (t_end) pt[4] += s0 - t_end; }
       // this wave's pieces of the tiles staged two steps ago (K(t+2), V(t)) have landed - last step's eight stay in flight - ...
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();                       // ... and everyone's; every wave finished step t - 1
       asm volatile("" ::: "memory");
+      if constexpr (DIAG & 4) s1 = stamp();
       char* kdst = kring + kst * K_TILE_BYTES + wid * 4096;
       char* vdst = vring + (vst == 0 ? 2 : vst - 1) * V_TILE_BYTES + wid * 4096;
       if (wave_on) {
@@ -1208,7 +1229,9 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         kdelta = kst == 2 ? -(K5_SLOTS - 1) * K_TILE_BYTES : K_TILE_BYTES;
         vdelta = vst == 2 ? -(V5_SLOTS - 1) * V_TILE_BYTES : V_TILE_BYTES;
         phase_a(std::integral_constant<int, 1 - P>{}, I1{}, I0{}, I1{}, kdst, vdst);
+        if constexpr (DIAG & 4) s2 = stamp();
         phase_b(std::integral_constant<int, 1 - P>{}, I1{});
+        if constexpr (DIAG & 4) { s3 = stamp(); pt[0] += s1 - s0; pt[1] += s2 - s1; pt[2] += s3 - s2; pt[3] += 1; t_end = s3; }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_k(i, kdst);
@@ -1223,11 +1246,19 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
 #pragma unroll 1
     for (; t + 1 < total_tiles; t += 2) { step(I0{}); step(I1{}); }
     if (t < total_tiles) step(I0{});
+    if constexpr (DIAG & 4) t_end = stamp() - k_t0;      // end of the tile loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA / look-ahead read may be in flight when the workgroup ends
     if (wave_on) keep_window();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last PV MFMAs -> the epilogue's accumulator reads
   }
   // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
+  int ovf = 0;
+  if (wave_on && total_tiles > 0) {
+    const bool bad0 = !(st[0].l > 5.4e-20f && st[0].l < 1.8e19f), bad1 = !(st[1].l > 5.4e-20f && st[1].l < 1.8e19f);     // 2^-64 .. 2^64, NaN is bad
+    const bool on0 = qbase + wid * 64 + fr < p.S, on1 = qbase + wid * 64 + 32 + fr < p.S;
+    ovf = __any((bad0 && on0) || (bad1 && on1)) ? 1 : 0;
+    if constexpr (DIAG & 3) ovf = 0;          // timing builds: no second pass
+  }
   if (lane == 0) wflags[wid] = ovf;
   __syncthreads();
   if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
@@ -1264,6 +1295,14 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
       }
   }
+  if constexpr (DIAG & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+      dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4];
+      dst[5] = __builtin_amdgcn_s_memtime() - k_t0; dst[6] = k_r0; dst[7] = pt[5] | (t_end << 32);
+    }
+  }
 }
 
 }  // namespace
@@ -1285,7 +1324,7 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   // ECHO_ATTN=4 / 5 select attn4_kernel / attn5_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention, then attn_kernel
   // for the (normally zero) workgroups whose scores left the fast kernels' range; both launches on the caller's stream.
   static const int variant = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : (getenv("ECHO_ATTN4") && atoi(getenv("ECHO_ATTN4")) ? 4 : 0);
-  if (!a.causal && !bias && !a.prof && (variant == 4 || variant == 5) && a.redo) {
+  if (!a.causal && !bias && (!a.prof || variant == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
     const dim3 g4((a.S + 255) / 256, a.H, a.rows);
@@ -1293,13 +1332,15 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
       if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
       hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
     } else {
-      const int di = diag == 1 ? 2 : diag == 2 ? 3 : diag == 3 ? 4 : 1;
-      const void* k5[5] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<1>, (const void*)attn5_kernel<2>, (const void*)attn5_kernel<3>};
+      const int di = a.prof ? 5 : diag == 19 ? 2 : diag == 35 ? 3 : diag == 3 ? 4 : 1;
+      const void* k5[6] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<19>, (const void*)attn5_kernel<35>, (const void*)attn5_kernel<3>,
+                           (const void*)attn5_kernel<4>};
       if (hipError_t e = ensure_dyn_lds(k5[di], SMEM5, prep4[di]); e != hipSuccess) return e;
       switch (di) {
-        case 2: hipLaunchKernelGGL(attn5_kernel<1>, g4, dim3(256), SMEM5, st, a); break;
-        case 3: hipLaunchKernelGGL(attn5_kernel<2>, g4, dim3(256), SMEM5, st, a); break;
+        case 2: hipLaunchKernelGGL(attn5_kernel<19>, g4, dim3(256), SMEM5, st, a); break;
+        case 3: hipLaunchKernelGGL(attn5_kernel<35>, g4, dim3(256), SMEM5, st, a); break;
         case 4: hipLaunchKernelGGL(attn5_kernel<3>, g4, dim3(256), SMEM5, st, a); break;
+        case 5: hipLaunchKernelGGL(attn5_kernel<4>, g4, dim3(256), SMEM5, st, a); break;
         default: hipLaunchKernelGGL(attn5_kernel<0>, g4, dim3(256), SMEM5, st, a);
       }
     }

@@ -209,8 +209,10 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
             sg.bias, sg.bias_row_stride = bias.data_ptr(), Lt
     L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
     torch.cuda.synchronize()
-    err = (out.float() - ref.reshape(R, S, H * 128)).abs()
-    assert float(err.max()) < 3e-2, float(err.max())
+    refr = ref.reshape(R, S, H * 128)
+    err = (out.float() - refr).abs()
+    # bf16 outputs: one ulp of a value in [4, 8) is 2^-5 - the bound is 3e-2 plus one bf16 ulp of the reference's magnitude
+    assert float((err - refr.abs() * 2.0 ** -7).max()) < 3e-2, float(err.max())
     assert float(err.mean()) < 2e-3, float(err.mean())
 
 

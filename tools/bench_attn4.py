@@ -51,6 +51,20 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
     ms = sorted(ts)[1]
     keys = sum(sum(r[i] for r in rows) for i in range(R))
     fl = 4.0 * S * keys * D
+    if os.environ.get("ECHO_ATTN") == "5" and os.environ.get("PROF"):
+        nw = ((S + 255) // 256) * H * R * 4
+        prof = torch.zeros((nw, 8), dtype=torch.int64, device=dev)
+        d.prof = prof.data_ptr()
+        L.check(lib.echo_op_attention_bf16(C.byref(d), U.stream()))
+        torch.cuda.synchronize()
+        d.prof = None
+        pr = prof.cpu().double()
+        pr = pr[pr[:, 3] > 0]
+        n = pr[:, 3]
+        x = prof.cpu()[prof.cpu()[:, 3] > 0][:, 7]
+        pro, loop_end = (x & 0xFFFFFFFF).double(), (x >> 32).double()
+        print("   attn5 per-step cycles (mean over waves): wait+barrier %.0f  phase A %.0f  phase B %.0f  step tail (walk) %.0f | steps/wave %.1f" % ((pr[:, 0] / n).mean(), (pr[:, 1] / n).mean(), (pr[:, 2] / n).mean(), (pr[:, 4] / n).mean(), n.mean()))
+        print("   per wave: setup + first tiles landed %.0f | + A(0), early(0) = loop start %.0f | loop end %.0f | wave end (O stored) %.0f cycles" % (pr[:, 6].mean(), pro.mean(), loop_end.mean(), pr[:, 5].mean()))
     print(f"attn {'v' + os.environ.get('ECHO_ATTN', '1')} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
 
 
