@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
 // reads at the end of step t already touch K(t+2)), so the per-step wait is vmcnt(8) - the previous step's eight pieces stay in flight.
 // Ring slots are not literals (the loop is unrolled by two, for the score buffers): the eight K and four V^T read addresses move by
 // one v_add each per step.  No LGKM drain at a step's end: the eight look-ahead reads stay in flight across the barrier.
-// The last step computes a dummy A(T) (the walk stays on the last tile): 32 MFMAs per workgroup.
+// The last step computes a dummy A(T) on whatever the K ring holds (a separate last-step path made hipcc spill): 32 MFMAs per workgroup.
 constexpr int K5_SLOTS = 4, V5_SLOTS = 3;
 constexpr int SMEM5 = K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16;
 
@@ -943,15 +943,20 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     const int qc = qi < p.S ? qi : p.S - 1;
     const bf16_t* qp = p.Q + (long)row * p.q_row_stride + (long)qc * p.q_ld + head * HD + 8 * fh;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 raw = *(const bf16x8*)(qp + 16 * kk);
-      f32x8 v = __builtin_convertvector(__builtin_bit_cast(hbf16x8, raw), f32x8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= p.scale * 1.4426950408889634f;
-      qf[qb][kk] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hbf16x8));
-      asm volatile("" : "+a"(qf[qb][kk]));          // from here on an accumulator-file value: no per-use copies
-    }
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + 16 * kk);      // requested here, scaled behind the first tiles' DMA issue
   }
+  auto scale_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        f32x8 v = __builtin_convertvector(__builtin_bit_cast(hbf16x8, qf[qb][kk]), f32x8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= p.scale * 1.4426950408889634f;
+        qf[qb][kk] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hbf16x8));
+        asm volatile("" : "+a"(qf[qb][kk]));          // from here on an accumulator-file value: no per-use copies
+      }
+  };
 
   int nkraw[4];
 #pragma unroll
@@ -1106,8 +1111,8 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     return lds_read16a(va[j >> 2], (j & 3) * 4096);
   };
   auto keep_window = [&]() __attribute__((always_inline)) {    // see attn4_kernel: a use of every in-flight read's destination behind the wait
+    static_assert(LA == 8, "the look-ahead reads without a consumer are fragments 0 .. LA - 1 of a phase that does not run");
     asm volatile("" ::"a"(fw[0]), "a"(fw[1]), "a"(fw[2]), "a"(fw[3]), "a"(fw[4]), "a"(fw[5]), "a"(fw[6]), "a"(fw[7]));
-    asm volatile("" ::"a"(fw[8]), "a"(fw[9]), "a"(fw[10]), "a"(fw[11]), "a"(fw[12]), "a"(fw[13]), "a"(fw[14]), "a"(fw[15]));
   };
   typedef std::integral_constant<int, 0> I0;
   typedef std::integral_constant<int, 1> I1;
@@ -1144,16 +1149,16 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     });
   };
   // phase B: O += V^T P for both streams; SOFT: first softmax half on buffer SB in the gaps.  The next phase is an A phase.
-  auto phase_b = [&](auto sbc, auto softc) __attribute__((always_inline)) {
+  auto phase_b = [&](auto sbc, auto softc, auto lastc) __attribute__((always_inline)) {
     constexpr int SB = decltype(sbc)::value;
-    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1);
+    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), LASTB = decltype(lastc)::value != 0;
     if constexpr (SOFT) { if (__builtin_expect(ragged, 0)) mask_tile(sbc); }
     sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kss = f >> 2, db = f & 3;
       constexpr int j = f + LA, nj = j >= 16 ? j - 16 : 0;
       if constexpr (j < 16) fw[j] = read_v(std::integral_constant<int, (j < 16 ? j : 0)>{});
-      else fw[nj] = read_k(std::integral_constant<int, nj>{});
-      lds_wait<LA>();
+      else if constexpr (!LASTB) fw[nj] = read_k(std::integral_constant<int, nj>{});
+      lds_wait<(LASTB && 15 - f < LA ? 15 - f : LA)>();
       if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SOFT) early(I0{}, sbc, fc);
@@ -1161,11 +1166,28 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SOFT) early(I1{}, sbc, fc);
-      if constexpr (f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
+      if constexpr (!LASTB && f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
   };
 
+  // gate values of the epilogue; stream 0's are requested in the last step between A and B (both streams' at once spill)
+  uint2 gq[2][4][4];
+  auto load_gate = [&](auto qbc) __attribute__((always_inline)) {
+    if (p.G) {
+      {
+        constexpr int qb = decltype(qbc)::value;
+        const int qi = qbase + wid * 64 + qb * 32 + fr;
+        const bf16_t* gp = p.G + (long)row * p.g_row_stride + (long)(qi < p.S ? qi : p.S - 1) * p.g_ld + head * HD + 4 * fh;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gq[qb][d][g] = *(const uint2*)(gp + 32 * d + 8 * g);
+      }
+    }
+  };
+  unsigned long long pa = 0, pb = 0, pc2 = 0;
+  if constexpr (DIAG & 4) pa = stamp() - k_t0;       // arguments, key counts, segment operands resolved; Q requested
   if (total_tiles > 0) {
     {
       int s0 = 0;
@@ -1194,7 +1216,9 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     for (int i = 0; i < 4; ++i) dma_k(i, kring + 3 * K_TILE_BYTES + wid * 4096);       // K(3) -> K slot 3
     x3 = lag_of();                                                                      // x3 = tile 3
     advance();                                                                          // w  = tile 4
-    if constexpr (DIAG & 4) pt[4] = 0;
+    if constexpr (DIAG & 4) { pt[4] = 0; pb = stamp() - k_t0; }     // first tiles' DMA issued
+    scale_q();
+    if constexpr (DIAG & 4) pc2 = stamp() - k_t0;                   // Q arrived and scaled                        // the Q loads were issued before the DMA pieces: their wait leaves those in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (DIAG & 4) k_r0 = stamp() - k_t0;     // (reused) setup + first tiles landed
@@ -1210,6 +1234,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early(I0{}, I0{}, ic); early(I1{}, I0{}, ic); });
     }
     if constexpr (DIAG & 4) pt[5] = stamp() - k_t0;      // prologue: setup, first tiles landed, A(0), early(0)
+    int t = 0;
     int kst = 0, vst = 0;    // t % 4, t % 3: K(t + 4) is staged into K slot kst, V^T(t + 2) into V slot (vst + 2) % 3
     // step t (P = t & 1): A(t+1) -> buffer 1 - P from the K slot ka points at | second half(t) on buffer P;  B(t) from the V slot va points at | first half(t+1)
     auto step = [&](auto pc) __attribute__((always_inline)) {
@@ -1217,6 +1242,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       if constexpr (DIAG & 4) { s0 = stamp(); if (t_end) pt[4] += s0 - t_end; }
       // this wave's pieces of the tiles staged two steps ago (K(t+2), V(t)) have landed - last step's eight stay in flight - ...
+      // (past the last tile the walk stays on it: the same eight pieces per step, a branch around them cost 440 cycles per step)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();                       // ... and everyone's; every wave finished step t - 1
       asm volatile("" ::: "memory");
@@ -1229,8 +1255,10 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         kdelta = kst == 2 ? -(K5_SLOTS - 1) * K_TILE_BYTES : K_TILE_BYTES;
         vdelta = vst == 2 ? -(V5_SLOTS - 1) * V_TILE_BYTES : V_TILE_BYTES;
         phase_a(std::integral_constant<int, 1 - P>{}, I1{}, I0{}, I1{}, kdst, vdst);
+        // the last step: the epilogue's gate values are requested here (the registers of the P just packed are free), B(T-1) covers part of their latency
+        if (__builtin_expect(t + 1 >= total_tiles, 0)) load_gate(I0{});
         if constexpr (DIAG & 4) s2 = stamp();
-        phase_b(std::integral_constant<int, 1 - P>{}, I1{});
+        phase_b(std::integral_constant<int, 1 - P>{}, I1{}, I0{});
         if constexpr (DIAG & 4) { s3 = stamp(); pt[0] += s1 - s0; pt[1] += s2 - s1; pt[2] += s3 - s2; pt[3] += 1; t_end = s3; }
       } else {
 #pragma unroll
@@ -1241,13 +1269,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       valid1 = x2.valid; x2 = x3; x3 = lag_of(); v_offsets(); advance();
       kst = kst == 3 ? 0 : kst + 1;
       vst = vst == 2 ? 0 : vst + 1;
+      ++t;
     };
-    int t = 0;
 #pragma unroll 1
-    for (; t + 1 < total_tiles; t += 2) { step(I0{}); step(I1{}); }
+    while (t + 1 < total_tiles) { step(I0{}); step(I1{}); }
     if (t < total_tiles) step(I0{});
     if constexpr (DIAG & 4) t_end = stamp() - k_t0;      // end of the tile loop
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA / look-ahead read may be in flight when the workgroup ends
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the look-ahead reads of a phase that does not run
     if (wave_on) keep_window();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last PV MFMAs -> the epilogue's accumulator reads
   }
@@ -1262,21 +1290,16 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   if (lane == 0) wflags[wid] = ovf;
   __syncthreads();
   if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
-  if (!wave_on) return;
+  if (!wave_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // no LDS-DMA may be in flight when a wave ends
+  if (total_tiles == 0) load_gate(I0{});
+  load_gate(I1{});                 // stream 1's gate values: their latency is covered by stream 0's rows
 
   // ---- epilogue: lane holds O[q = 32 qb + fr][32 d + 8 g + 4 fh + 0..3]; gate values requested as one batch per query stream
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int q = qbase + wid * 64 + qb * 32 + fr;
     if (q >= p.S) continue;
-    uint2 gq[4][4];
-    const bf16_t* gp = p.G ? p.G + (long)row * p.g_row_stride + (long)q * p.g_ld + head * HD + 4 * fh : nullptr;
-    if (gp) {
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gq[d][g] = *(const uint2*)(gp + 32 * d + 8 * g);
-    }
+    const bool gp = p.G != nullptr;
     const float inv_l = 1.0f / st[qb].l;
     bf16_t* op = p.O + (long)row * p.o_row_stride + (long)q * p.o_ld + head * HD + 4 * fh;
 #pragma unroll
@@ -1288,18 +1311,18 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[qb][d][4 * g + i] * inv_l));
         if (gp) {
           float gv[4];
-          Vec4<bf16_t>::unpack(gq[d][g], gv);
+          Vec4<bf16_t>::unpack(gq[qb][d][g], gv);
 #pragma unroll
           for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
         }
         *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last steps' LDS-DMA (tiles past the end) must not outlive the workgroup's LDS
   if constexpr (DIAG & 4) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
       unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
-      dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4];
+      dst[0] = pt[0]; dst[1] = pt[1] | (pa << 40); dst[2] = pt[2] | (pb << 40); dst[3] = pt[3]; dst[4] = pt[4] | (pc2 << 40);
       dst[5] = __builtin_amdgcn_s_memtime() - k_t0; dst[6] = k_r0; dst[7] = pt[5] | (t_end << 32);
     }
   }
@@ -1323,8 +1346,13 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
   // ECHO_ATTN=4 / 5 select attn4_kernel / attn5_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention, then attn_kernel
   // for the (normally zero) workgroups whose scores left the fast kernels' range; both launches on the caller's stream.
-  static const int variant = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : (getenv("ECHO_ATTN4") && atoi(getenv("ECHO_ATTN4")) ? 4 : 0);
-  if (!a.causal && !bias && (!a.prof || variant == 5) && (variant == 4 || variant == 5) && a.redo) {
+  // Default: attn5_kernel when its grid fills the chip (>= 256 workgroups of 256 queries: from 6 rows x 16 heads x 640 queries on), else
+  // attn_kernel, whose two workgroups per CU hide the per-workgroup prologue / epilogue that attn5_kernel's single one exposes (measured,
+  // tools/bench_attn4.py, us: 24 rows 236 vs 268, 12 rows 132 vs 138, 8 rows 108 vs 114, 3 rows 54 vs 42).  ECHO_ATTN=1 / 4 / 5 force a kernel.
+  static const int forced = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : 0;
+  const long wg5 = (long)((a.S + 255) / 256) * a.H * a.rows;
+  const int variant = forced ? forced : (wg5 >= 256 ? 5 : 1);
+  if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
     const dim3 g4((a.S + 255) / 256, a.H, a.rows);

@@ -216,10 +216,10 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
     assert float(err.mean()) < 2e-3, float(err.mean())
 
 
-@pytest.mark.parametrize("variant", ["4", "5"])
+@pytest.mark.parametrize("variant", ["1", "4", "5"])
 def test_attention_fast_kernel_variant(variant):
-    """attn4_kernel / attn5_kernel (ECHO_ATTN=4 / 5, read once per process): the joint-segment cases incl. the range-fallback spikes and
-    the tile counts of every remainder class of their unrolled loops, in a child process."""
+    """attn_kernel / attn4_kernel / attn5_kernel forced (ECHO_ATTN=1 / 4 / 5, read once per process; the default picks by grid size): the
+    joint-segment cases incl. the range-fallback spikes and the tile counts of every remainder class of their unrolled loops, in a child process."""
     import os, subprocess, sys
     if os.environ.get("ECHO_ATTN"):
         pytest.skip("already a variant run")

@@ -58,12 +58,16 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
         L.check(lib.echo_op_attention_bf16(C.byref(d), U.stream()))
         torch.cuda.synchronize()
         d.prof = None
-        pr = prof.cpu().double()
-        pr = pr[pr[:, 3] > 0]
+        raw = prof.cpu()
+        raw = raw[raw[:, 3] > 0]
+        pa, pb, pc = (raw[:, 1] >> 40).double().mean(), (raw[:, 2] >> 40).double().mean(), (raw[:, 4] >> 40).double().mean()
+        pr = (raw & ((1 << 40) - 1)).double()
+        pr[:, 5:] = raw[:, 5:].double()
         n = pr[:, 3]
-        x = prof.cpu()[prof.cpu()[:, 3] > 0][:, 7]
+        x = raw[:, 7]
         pro, loop_end = (x & 0xFFFFFFFF).double(), (x >> 32).double()
         print("   attn5 per-step cycles (mean over waves): wait+barrier %.0f  phase A %.0f  phase B %.0f  step tail (walk) %.0f | steps/wave %.1f" % ((pr[:, 0] / n).mean(), (pr[:, 1] / n).mean(), (pr[:, 2] / n).mean(), (pr[:, 4] / n).mean(), n.mean()))
+        print("   prologue: setup done %.0f | DMA issued %.0f | Q scaled %.0f" % (pa, pb, pc))
         print("   per wave: setup + first tiles landed %.0f | + A(0), early(0) = loop start %.0f | loop end %.0f | wave end (O stored) %.0f cycles" % (pr[:, 6].mean(), pro.mean(), loop_end.mean(), pr[:, 5].mean()))
     print(f"attn {'v' + os.environ.get('ECHO_ATTN', '1')} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
 
