@@ -898,6 +898,9 @@ __device__ __forceinline__ void mfma_sa_next(f32x16& s, const bf16x8& kf, const 
 __device__ __forceinline__ void mfma_pv(f32x16& o, const bf16x8& vf, const bf16x8& pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "a"(vf), "v"(pf));
 }
+__device__ __forceinline__ void mfma_pv_vv(f32x16& o, const bf16x8& vf, const bf16x8& pf) {      // timing experiment: A from an arch VGPR
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pf));
+}
 
 // eight fp32 -> bf16x8 with exactly four v_cvt_pk_bf16_f32 (hipcc sometimes converts the elements one by one and merges with v_perm_b32)
 __device__ __forceinline__ bf16x8 pack8_asm(const f32x16& s, int base) {
@@ -1159,11 +1162,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       if constexpr (j < 16) fw[j] = read_v(std::integral_constant<int, (j < 16 ? j : 0)>{});
       else if constexpr (!LASTB) fw[nj] = read_k(std::integral_constant<int, nj>{});
       lds_wait<(LASTB && 15 - f < LA ? 15 - f : LA)>();
-      if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
+      if constexpr (DIAG & 64) { mfma_pv_vv(o[0][db], __builtin_bit_cast(bf16x8, st[1].pf[kss]), __builtin_bit_cast(bf16x8, st[0].pf[kss])); asm volatile("" ::"a"(fw[f])); }
+      else if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SOFT) early(I0{}, sbc, fc);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
+      if constexpr (DIAG & 64) mfma_pv_vv(o[1][db], __builtin_bit_cast(bf16x8, st[0].pf[kss]), __builtin_bit_cast(bf16x8, st[1].pf[kss]));
+      else if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SOFT) early(I1{}, sbc, fc);
       if constexpr (!LASTB && f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
@@ -1360,13 +1365,13 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
       if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
       hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
     } else {
-      const int di = a.prof ? 5 : diag == 19 ? 2 : diag == 35 ? 3 : diag == 3 ? 4 : 1;
-      const void* k5[6] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<19>, (const void*)attn5_kernel<35>, (const void*)attn5_kernel<3>,
+      const int di = a.prof ? (diag == 5 ? 2 : diag == 6 ? 3 : 5) : diag == 3 ? 4 : 1;
+      const void* k5[6] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<5>, (const void*)attn5_kernel<6>, (const void*)attn5_kernel<3>,
                            (const void*)attn5_kernel<4>};
       if (hipError_t e = ensure_dyn_lds(k5[di], SMEM5, prep4[di]); e != hipSuccess) return e;
       switch (di) {
-        case 2: hipLaunchKernelGGL(attn5_kernel<19>, g4, dim3(256), SMEM5, st, a); break;
-        case 3: hipLaunchKernelGGL(attn5_kernel<35>, g4, dim3(256), SMEM5, st, a); break;
+        case 2: hipLaunchKernelGGL(attn5_kernel<5>, g4, dim3(256), SMEM5, st, a); break;
+        case 3: hipLaunchKernelGGL(attn5_kernel<6>, g4, dim3(256), SMEM5, st, a); break;
         case 4: hipLaunchKernelGGL(attn5_kernel<3>, g4, dim3(256), SMEM5, st, a); break;
         case 5: hipLaunchKernelGGL(attn5_kernel<4>, g4, dim3(256), SMEM5, st, a); break;
         default: hipLaunchKernelGGL(attn5_kernel<0>, g4, dim3(256), SMEM5, st, a);
