@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   if (PROF) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
   // second pass behind attn4_kernel: only the 256-query blocks it flagged are done again here (with per-tile rescaling)
-  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * ((gridDim.x + 1) >> 1) + (blockIdx.x >> 1)] == 0) return;
+  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.redo_nb + ((blockIdx.x + p.q_block0) >> 1)] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wid & 3, kh = wid >> 2;
   const int row = blockIdx.z, head = blockIdx.y;
-  const int qbase = blockIdx.x * QT;
+  const int qbase = (blockIdx.x + p.q_block0) * QT;
   const int fr = lane & 31, fh = lane >> 5;
   const int q = qbase + qb * 32 + fr;
   const bool q_ok = q < p.S;
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
   // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
   if (lane == 0) wflags[wid] = ovf;
   __syncthreads();
-  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
+  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * p.redo_nb + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
   if (!wave_on) return;
 
   // ---- epilogue: lane holds O[q = 32 qb + fr][32 d + 8 g + 4 fh + 0..3]; gate values requested as one batch per query stream
@@ -1072,10 +1072,16 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   };
   // early(): element g of the kb = 0 half: P = exp2(S), row sum.  late(): element g of the kb = 1 half, one v_cvt_pk of finished pairs
   // (kb 0 pairs in gaps 0-7, kb 1 pair g - 8 in gaps 8-15), and the denominator in gap 15.
-  auto early = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
+  // The pieces are placed by hand (tools/micro/mfma_fill.hip: one wave issues in order - MFMA 8 cycles, v_exp_f32 10, v_add / v_cvt_pk
+  // 4.5, ds_read_b128 + counted wait 19 with four waves reading, an LDS-DMA piece ~24 - and an MFMA takes 32: what sits between two
+  // MFMAs must add up to <= 24): behind the first MFMA of a pair exp(stream 0), add(stream 0), exp(stream 1); behind the second
+  // add(stream 1), the packing / DMA piece, and the next pair's fragment read.
+  auto early_exp = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
     constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
-    const float x = __builtin_amdgcn_exp2f(sc[b][q][0][g]);       // its add comes one element later: no wait state behind the v_exp
-    sc[b][q][0][g] = x;
+    sc[b][q][0][g] = __builtin_amdgcn_exp2f(sc[b][q][0][g]);
+  };
+  auto early_add = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {      // one element late: no wait state behind the v_exp
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
     if constexpr (g == 1) st[q].rs = sc[b][q][0][0];
     else if constexpr (g > 1) st[q].rs += sc[b][q][0][g - 1];
   };
@@ -1086,16 +1092,21 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     const f32x2 v = {sc[b][q][kb][2 * j], sc[b][q][kb][2 * j + 1]};
     st[q].pf[2 * kb + (j >> 2)][j & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));   // one v_cvt_pk_bf16_f32
   };
-  auto late = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
+  auto late_exp = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
     constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
-    const float x = __builtin_amdgcn_exp2f(sc[b][q][1][g]);
-    sc[b][q][1][g] = x;
+    sc[b][q][1][g] = __builtin_amdgcn_exp2f(sc[b][q][1][g]);
+  };
+  auto late_add = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
     if constexpr (g == 0) st[q].rs += sc[b][q][0][15]; else st[q].rs += sc[b][q][1][g - 1];
+  };
+  auto late_cvt = [&](auto qc_, auto bc_, auto gc_) __attribute__((always_inline)) {       // kb 0 pairs in gaps 0-7, kb 1 pair g - 8 in gaps 8-15
+    constexpr int q = decltype(qc_)::value, b = decltype(bc_)::value, g = decltype(gc_)::value;
     if constexpr (g < 8) cvt_pair(qc_, bc_, std::integral_constant<int, 0>{}, gc_);
     else cvt_pair(qc_, bc_, std::integral_constant<int, 1>{}, std::integral_constant<int, (g >= 8 ? g - 8 : 0)>{});
     if constexpr (g == 15) {
       cvt_pair(qc_, bc_, std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{});
-      st[q].l += half_sum(st[q].rs + x);
+      st[q].l += half_sum(st[q].rs + sc[b][q][1][15]);
     }
   };
 
@@ -1122,10 +1133,11 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   int kdelta = K_TILE_BYTES, vdelta = V_TILE_BYTES;       // what moves ka / va to the ring slot of the next A / B phase
 
   // phase A: scores of one tile for both streams into buffer NB.  SOFT: second softmax half on buffer 1 - NB in the gaps.  NEXTA: the
-  // next MFMA phase is again an A phase (prologue), else phase B.  DMA: this wave's 4 K + 4 V^T pieces at even gaps.
-  auto phase_a = [&](auto nbc, auto softc, auto nextac, auto dmac, char* kdst, char* vdst) __attribute__((always_inline)) {
+  // next MFMA phase is again an A phase (prologue), else phase B.
+  auto phase_a = [&](auto nbc, auto softc, auto nextac) __attribute__((always_inline)) {
     constexpr int NB = decltype(nbc)::value;
-    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), NEXTA = decltype(nextac)::value != 0, DMA = decltype(dmac)::value != 0;
+    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), NEXTA = decltype(nextac)::value != 0;
+    typedef std::integral_constant<int, 1 - NB> OB;
     sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kb = f >> 3, kk = f & 7;
       constexpr int j = f + LA, nj = j >= 16 ? j - 16 : 0;
@@ -1139,22 +1151,21 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][0][kb], fw[f], qf[0][kk]); else mfma_sa_next(sc[NB][0][kb], fw[f], qf[0][kk]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) late(I0{}, std::integral_constant<int, 1 - NB>{}, fc);
-      if constexpr (DMA && (f & 1) == 0 && !(DIAG & 16)) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }
+      if constexpr (SOFT) { late_exp(I0{}, OB{}, fc); late_add(I0{}, OB{}, fc); late_exp(I1{}, OB{}, fc); }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(DIAG & 2)) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][1][kb], fw[f], qf[1][kk]); else mfma_sa_next(sc[NB][1][kb], fw[f], qf[1][kk]);
       } else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) late(I1{}, std::integral_constant<int, 1 - NB>{}, fc);
+      if constexpr (SOFT) { late_add(I1{}, OB{}, fc); late_cvt(I0{}, OB{}, fc); late_cvt(I1{}, OB{}, fc); }
       if constexpr (!NEXTA && f >= 16 - LA && f < 24 - LA) ka[f - (16 - LA)] += kdelta;      // every read of this K slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   // phase B: O += V^T P for both streams; SOFT: first softmax half on buffer SB in the gaps.  The next phase is an A phase.
-  auto phase_b = [&](auto sbc, auto softc, auto lastc) __attribute__((always_inline)) {
+  auto phase_b = [&](auto sbc, auto softc, auto lastc, auto dmac, char* kdst, char* vdst) __attribute__((always_inline)) {
     constexpr int SB = decltype(sbc)::value;
-    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), LASTB = decltype(lastc)::value != 0;
+    constexpr bool SOFT = decltype(softc)::value != 0 && !(DIAG & 1), LASTB = decltype(lastc)::value != 0, DMA = decltype(dmac)::value != 0;
     if constexpr (SOFT) { if (__builtin_expect(ragged, 0)) mask_tile(sbc); }
     sfor<0, 16>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kss = f >> 2, db = f & 3;
@@ -1165,12 +1176,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       if constexpr (DIAG & 64) { mfma_pv_vv(o[0][db], __builtin_bit_cast(bf16x8, st[1].pf[kss]), __builtin_bit_cast(bf16x8, st[0].pf[kss])); asm volatile("" ::"a"(fw[f])); }
       else if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) early(I0{}, sbc, fc);
+      if constexpr (SOFT) { early_exp(I0{}, sbc, fc); early_add(I0{}, sbc, fc); early_exp(I1{}, sbc, fc); }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DIAG & 64) mfma_pv_vv(o[1][db], __builtin_bit_cast(bf16x8, st[0].pf[kss]), __builtin_bit_cast(bf16x8, st[1].pf[kss]));
       else if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) early(I1{}, sbc, fc);
+      if constexpr (SOFT) early_add(I1{}, sbc, fc);
+      if constexpr (DMA && (f & 1) == 0 && !(DIAG & 16)) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }     // this wave's 4 K + 4 V^T pieces
       if constexpr (!LASTB && f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1232,11 +1244,11 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       sfor<0, LA>([&](auto jc) __attribute__((always_inline)) { fw[decltype(jc)::value] = read_k(jc); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       kdelta = K_TILE_BYTES;
-      phase_a(I0{}, I0{}, I1{}, I0{}, kring, vring);
+      phase_a(I0{}, I0{}, I1{});
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> vector ALU: hipcc pads nothing behind an asm MFMA
       mask_l = valid0 - 8 * fh;
       if (valid0 < KT) mask_tile(I0{});
-      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early(I0{}, I0{}, ic); early(I1{}, I0{}, ic); });
+      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early_exp(I0{}, I0{}, ic); early_add(I0{}, I0{}, ic); early_exp(I1{}, I0{}, ic); early_add(I1{}, I0{}, ic); });
     }
     if constexpr (DIAG & 4) pt[5] = stamp() - k_t0;      // prologue: setup, first tiles landed, A(0), early(0)
     int t = 0;
@@ -1245,13 +1257,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     auto step = [&](auto pc) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      if constexpr (DIAG & 4) { s0 = stamp(); if (t_end) pt[4] += s0 - t_end; }
+      if constexpr ((DIAG & 4) && !(DIAG & 128)) { s0 = stamp(); if (t_end) pt[4] += s0 - t_end; }
       // this wave's pieces of the tiles staged two steps ago (K(t+2), V(t)) have landed - last step's eight stay in flight - ...
       // (past the last tile the walk stays on it: the same eight pieces per step, a branch around them cost 440 cycles per step)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();                       // ... and everyone's; every wave finished step t - 1
       asm volatile("" ::: "memory");
-      if constexpr (DIAG & 4) s1 = stamp();
+      if constexpr ((DIAG & 4) && !(DIAG & 128)) s1 = stamp();
       char* kdst = kring + kst * K_TILE_BYTES + wid * 4096;
       char* vdst = vring + (vst == 0 ? 2 : vst - 1) * V_TILE_BYTES + wid * 4096;
       if (wave_on) {
@@ -1259,12 +1271,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         mask_l = valid1 - 8 * fh;
         kdelta = kst == 2 ? -(K5_SLOTS - 1) * K_TILE_BYTES : K_TILE_BYTES;
         vdelta = vst == 2 ? -(V5_SLOTS - 1) * V_TILE_BYTES : V_TILE_BYTES;
-        phase_a(std::integral_constant<int, 1 - P>{}, I1{}, I0{}, I1{}, kdst, vdst);
+        phase_a(std::integral_constant<int, 1 - P>{}, I1{}, I0{});
         // the last step: the epilogue's gate values are requested here (the registers of the P just packed are free), B(T-1) covers part of their latency
         if (__builtin_expect(t + 1 >= total_tiles, 0)) load_gate(I0{});
-        if constexpr (DIAG & 4) s2 = stamp();
-        phase_b(std::integral_constant<int, 1 - P>{}, I1{}, I0{});
-        if constexpr (DIAG & 4) { s3 = stamp(); pt[0] += s1 - s0; pt[1] += s2 - s1; pt[2] += s3 - s2; pt[3] += 1; t_end = s3; }
+        if constexpr ((DIAG & 4) && !(DIAG & 128)) s2 = stamp();
+        phase_b(std::integral_constant<int, 1 - P>{}, I1{}, I0{}, I1{}, kdst, vdst);
+        if constexpr ((DIAG & 4) && !(DIAG & 128)) { s3 = stamp(); pt[0] += s1 - s0; pt[1] += s2 - s1; pt[2] += s3 - s2; pt[3] += 1; t_end = s3; }
+        else if constexpr (DIAG & 4) pt[3] += 1;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_k(i, kdst);
@@ -1294,7 +1307,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   }
   if (lane == 0) wflags[wid] = ovf;
   __syncthreads();
-  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * gridDim.x + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
+  if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * p.redo_nb + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
   if (!wave_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // no LDS-DMA may be in flight when a wave ends
   if (total_tiles == 0) load_gate(I0{});
   load_gate(I1{});                 // stream 1's gate values: their latency is covered by stream 0's rows
@@ -1360,33 +1373,50 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
-    const dim3 g4((a.S + 255) / 256, a.H, a.rows);
+    // A last block of at most 128 queries (S = 640: queries 512..639) would leave two of a 256-query workgroup's four waves idle: it goes to
+    // attn_kernel (128 queries per workgroup) in a second launch.  24 rows x 16 heads: 768 fast workgroups = three full rounds of the chip.
+    const int nb256 = (a.S + 255) / 256;
+    const int rem = a.S - (nb256 - 1) * 256;
+    const int nfast = (variant == 5 && diag == 0 && nb256 > 1 && rem <= 128) ? nb256 - 1 : nb256;
+    AttnArgs f = a;
+    f.redo_nb = nb256;
+    f.q_block0 = 0;
+    const dim3 g4(nfast, a.H, a.rows);
     if (variant == 4) {
       if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
-      hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, a);
+      hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, f);
     } else {
-      const int di = a.prof ? (diag == 5 ? 2 : diag == 6 ? 3 : 5) : diag == 3 ? 4 : 1;
-      const void* k5[6] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<5>, (const void*)attn5_kernel<6>, (const void*)attn5_kernel<3>,
+      const int di = a.prof ? (diag == 132 ? 2 : diag == 6 ? 3 : 5) : diag == 3 ? 4 : 1;
+      const void* k5[6] = {nullptr, (const void*)attn5_kernel<0>, (const void*)attn5_kernel<132>, (const void*)attn5_kernel<6>, (const void*)attn5_kernel<3>,
                            (const void*)attn5_kernel<4>};
       if (hipError_t e = ensure_dyn_lds(k5[di], SMEM5, prep4[di]); e != hipSuccess) return e;
       switch (di) {
-        case 2: hipLaunchKernelGGL(attn5_kernel<5>, g4, dim3(256), SMEM5, st, a); break;
-        case 3: hipLaunchKernelGGL(attn5_kernel<6>, g4, dim3(256), SMEM5, st, a); break;
-        case 4: hipLaunchKernelGGL(attn5_kernel<3>, g4, dim3(256), SMEM5, st, a); break;
-        case 5: hipLaunchKernelGGL(attn5_kernel<4>, g4, dim3(256), SMEM5, st, a); break;
-        default: hipLaunchKernelGGL(attn5_kernel<0>, g4, dim3(256), SMEM5, st, a);
+        case 2: hipLaunchKernelGGL(attn5_kernel<132>, g4, dim3(256), SMEM5, st, f); break;
+        case 3: hipLaunchKernelGGL(attn5_kernel<6>, g4, dim3(256), SMEM5, st, f); break;
+        case 4: hipLaunchKernelGGL(attn5_kernel<3>, g4, dim3(256), SMEM5, st, f); break;
+        case 5: hipLaunchKernelGGL(attn5_kernel<4>, g4, dim3(256), SMEM5, st, f); break;
+        default: hipLaunchKernelGGL(attn5_kernel<0>, g4, dim3(256), SMEM5, st, f);
       }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    AttnArgs b = a;
+    AttnArgs b = f;
+    b.prof = nullptr;
+    if (nfast < nb256) {                         // the short last block: attn_kernel, its blocks 2 nfast ..
+      b.q_block0 = 2 * nfast;
+      hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(grid.x - 2 * nfast, a.H, a.rows), dim3(512), SMEM, st, b);
+      if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    b.q_block0 = 0;                              // second pass over the fast kernels' blocks: only the flagged ones do anything
     b.redo_filter = a.redo;
-    hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(512), SMEM, st, b);
+    hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(min((int)grid.x, 2 * nfast), a.H, a.rows), dim3(512), SMEM, st, b);
     return hipGetLastError();
   }
-  if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(512), SMEM, st, a);   // s_memtime stamps
-  else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(512), SMEM, st, a);
-  else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(512), SMEM, st, a);
-  else if (bias) hipLaunchKernelGGL((attn_kernel<false, true, false>), grid, dim3(512), SMEM, st, a);
-  else hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(512), SMEM, st, a);
+  AttnArgs a0 = a;
+  a0.q_block0 = 0; a0.redo_nb = 0; a0.redo_filter = nullptr;
+  if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(512), SMEM, st, a0);   // s_memtime stamps
+  else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(512), SMEM, st, a0);
+  else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(512), SMEM, st, a0);
+  else if (bias) hipLaunchKernelGGL((attn_kernel<false, true, false>), grid, dim3(512), SMEM, st, a0);
+  else hipLaunchKernelGGL((attn_kernel<false, false, false>), grid, dim3(512), SMEM, st, a0);
   return hipGetLastError();
 }

@@ -160,6 +160,8 @@ struct AttnArgs {
   // non-zero = a score left its fixed-reference range and attn_kernel must redo that block; nullptr = attn_kernel only.
   int* redo;
   const int* redo_filter;       // set by the launcher on attn_kernel's second pass
+  int q_block0;                 // set by the launcher: attn_kernel's first 128-query block (blockIdx.x counts from it)
+  int redo_nb;                  // set by the launcher: 256-query blocks per (row, head) in `redo`
 };
 inline long attn_redo_words(int rows, int H, int S) { return (long)rows * H * ((S + 255) / 256); }
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);

@@ -68,10 +68,11 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
         pro, loop_end = (x & 0xFFFFFFFF).double(), (x >> 32).double()
         print("   attn5 per-step cycles (mean over waves): wait+barrier %.0f  phase A %.0f  phase B %.0f  step tail (walk) %.0f | steps/wave %.1f" % ((pr[:, 0] / n).mean(), (pr[:, 1] / n).mean(), (pr[:, 2] / n).mean(), (pr[:, 4] / n).mean(), n.mean()))
         print("   prologue: setup done %.0f | DMA issued %.0f | Q scaled %.0f" % (pa, pb, pc))
+        print("   cycles per step incl. everything between the loop's first and last stamp: %.0f" % ((loop_end - pro) / n).mean())
         print("   per wave: setup + first tiles landed %.0f | + A(0), early(0) = loop start %.0f | loop end %.0f | wave end (O stored) %.0f cycles" % (pr[:, 6].mean(), pro.mean(), loop_end.mean(), pr[:, 5].mean()))
     print(f"attn {'v' + os.environ.get('ECHO_ATTN', '1')} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
 
 
 if __name__ == "__main__":
-    for R in ((24, 1) if os.environ.get("ECHO_ATTN_DIAG") else (24, 12, 8, 3, 1)):
+    for R in ((24, 1) if os.environ.get("ECHO_ATTN_DIAG") else (24, 12, 8, 6, 4, 3, 1)):
         run(R)
