@@ -898,9 +898,6 @@ __device__ __forceinline__ void mfma_sa_next(f32x16& s, const bf16x8& kf, const 
 __device__ __forceinline__ void mfma_pv(f32x16& o, const bf16x8& vf, const bf16x8& pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "a"(vf), "v"(pf));
 }
-__device__ __forceinline__ void mfma_pv_vv(f32x16& o, const bf16x8& vf, const bf16x8& pf) {      // timing experiment: A from an arch VGPR
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pf));
-}
 
 // eight fp32 -> bf16x8 with exactly four v_cvt_pk_bf16_f32 (hipcc sometimes converts the elements one by one and merges with v_perm_b32)
 __device__ __forceinline__ bf16x8 pack8_asm(const f32x16& s, int base) {
@@ -923,8 +920,10 @@ struct Soft5 {           // softmax state of one query stream (the scores live i
 
 // DIAG bits (timing experiments): 1 = no softmax VALU work, 2 = no MFMAs, 8 = linear (trivially conflict-free) fragment addresses (all three:
 // wrong results), 16 = no LDS-DMA in the loop, 32 = no LDS reads, 4 = s_memtime stamps per phase into p.prof
-template <int DIAG>
-__global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
+// NS = query streams per wave: 2 (256 queries per workgroup), or 1 for a last block of at most 128 queries (four waves x 32 queries, one MFMA per
+// fragment: no wave idles; the same code with the second stream compiled out)
+template <int DIAG, int NS>
+__device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t_end = 0;
   if constexpr (DIAG & 4) k_t0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [4][16 KiB] | V ring [3][16 KiB] | 4 range flags
@@ -934,15 +933,16 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   const int row = blockIdx.z, head = blockIdx.y;
   const int qbase = blockIdx.x * QW;
   const int fr = lane & 31, fh = lane >> 5;
-  const bool wave_on = qbase + wid * 64 < p.S;          // wave-uniform: a wave without queries only stages tiles
+  constexpr int WQ = 32 * NS;                            // queries per wave
+  const bool wave_on = qbase + wid * WQ < p.S;          // wave-uniform: a wave without queries only stages tiles
   char* const kring = smem;
   char* const vring = smem + K5_SLOTS * K_TILE_BYTES;
   int* const wflags = (int*)(smem + K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES);
 
   bf16x8 qf[2][8];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qi = qbase + wid * 64 + qb * 32 + fr;
+  for (int qb = 0; qb < NS; ++qb) {
+    const int qi = qbase + wid * WQ + qb * 32 + fr;
     const int qc = qi < p.S ? qi : p.S - 1;
     const bf16_t* qp = p.Q + (long)row * p.q_row_stride + (long)qc * p.q_ld + head * HD + 8 * fh;
 #pragma unroll
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   }
   auto scale_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NS; ++qb)
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         f32x8 v = __builtin_convertvector(__builtin_bit_cast(hbf16x8, qf[qb][kk]), f32x8);
@@ -1045,7 +1045,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   f32x16 sc[2][2][2];        // [buffer][stream][kb] exp2 arguments / P of a tile: arch VGPRs (asm "=&v" / "+v")
   Soft5 st[2];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < NS; ++qb) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -1063,7 +1063,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     constexpr int b = decltype(bc_)::value;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     const float gone = -1e30f;
-    sfor<0, 64>([&](auto ec) __attribute__((always_inline)) {
+    sfor<0, 32 * NS>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value, q = e >> 5, kb = (e >> 4) & 1, r = e & 15;
       float x = sc[b][q][kb][r];
       asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(x) : "v"(mask_l), "n"(32 * kb + 16 * (r >> 3) + (r & 7)), "v"(gone) : "vcc");
@@ -1151,13 +1151,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][0][kb], fw[f], qf[0][kk]); else mfma_sa_next(sc[NB][0][kb], fw[f], qf[0][kk]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) { late_exp(I0{}, OB{}, fc); late_add(I0{}, OB{}, fc); late_exp(I1{}, OB{}, fc); }
+      if constexpr (SOFT) { late_exp(I0{}, OB{}, fc); late_add(I0{}, OB{}, fc); if constexpr (NS == 2) late_exp(I1{}, OB{}, fc); else late_cvt(I0{}, OB{}, fc); }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(DIAG & 2)) {
+      if constexpr (!(DIAG & 2) && NS == 2) {
         if constexpr (kk == 0) mfma_sa_first(sc[NB][1][kb], fw[f], qf[1][kk]); else mfma_sa_next(sc[NB][1][kb], fw[f], qf[1][kk]);
-      } else asm volatile("" ::"a"(fw[f]));
+      } else if constexpr (DIAG & 2) asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) { late_add(I1{}, OB{}, fc); late_cvt(I0{}, OB{}, fc); late_cvt(I1{}, OB{}, fc); }
+      if constexpr (SOFT && NS == 2) { late_add(I1{}, OB{}, fc); late_cvt(I0{}, OB{}, fc); late_cvt(I1{}, OB{}, fc); }
       if constexpr (!NEXTA && f >= 16 - LA && f < 24 - LA) ka[f - (16 - LA)] += kdelta;      // every read of this K slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1173,15 +1173,13 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       if constexpr (j < 16) fw[j] = read_v(std::integral_constant<int, (j < 16 ? j : 0)>{});
       else if constexpr (!LASTB) fw[nj] = read_k(std::integral_constant<int, nj>{});
       lds_wait<(LASTB && 15 - f < LA ? 15 - f : LA)>();
-      if constexpr (DIAG & 64) { mfma_pv_vv(o[0][db], __builtin_bit_cast(bf16x8, st[1].pf[kss]), __builtin_bit_cast(bf16x8, st[0].pf[kss])); asm volatile("" ::"a"(fw[f])); }
-      else if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
+      if constexpr (!(DIAG & 2)) mfma_pv(o[0][db], fw[f], __builtin_bit_cast(bf16x8, st[0].pf[kss]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) { early_exp(I0{}, sbc, fc); early_add(I0{}, sbc, fc); early_exp(I1{}, sbc, fc); }
+      if constexpr (SOFT) { early_exp(I0{}, sbc, fc); early_add(I0{}, sbc, fc); if constexpr (NS == 2) early_exp(I1{}, sbc, fc); }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DIAG & 64) mfma_pv_vv(o[1][db], __builtin_bit_cast(bf16x8, st[0].pf[kss]), __builtin_bit_cast(bf16x8, st[1].pf[kss]));
-      else if constexpr (!(DIAG & 2)) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else asm volatile("" ::"a"(fw[f]));
+      if constexpr (!(DIAG & 2) && NS == 2) mfma_pv(o[1][db], fw[f], __builtin_bit_cast(bf16x8, st[1].pf[kss])); else if constexpr (DIAG & 2) asm volatile("" ::"a"(fw[f]));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SOFT) early_add(I1{}, sbc, fc);
+      if constexpr (SOFT && NS == 2) early_add(I1{}, sbc, fc);
       if constexpr (DMA && (f & 1) == 0 && !(DIAG & 16)) { if constexpr (f < 8) dma_k(f >> 1, kdst); else dma_v((f - 8) >> 1, vdst); }     // this wave's 4 K + 4 V^T pieces
       if constexpr (!LASTB && f >= 16 - LA && f < 20 - LA) va[f - (16 - LA)] += vdelta;        // every read of this V slot is issued: on to the next one
       __builtin_amdgcn_sched_barrier(0);
@@ -1194,7 +1192,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
     if (p.G) {
       {
         constexpr int qb = decltype(qbc)::value;
-        const int qi = qbase + wid * 64 + qb * 32 + fr;
+        const int qi = qbase + wid * WQ + qb * 32 + fr;
         const bf16_t* gp = p.G + (long)row * p.g_row_stride + (long)(qi < p.S ? qi : p.S - 1) * p.g_ld + head * HD + 4 * fh;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -1248,7 +1246,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> vector ALU: hipcc pads nothing behind an asm MFMA
       mask_l = valid0 - 8 * fh;
       if (valid0 < KT) mask_tile(I0{});
-      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early_exp(I0{}, I0{}, ic); early_add(I0{}, I0{}, ic); early_exp(I1{}, I0{}, ic); early_add(I1{}, I0{}, ic); });
+      if constexpr (!(DIAG & 1)) sfor<0, 16>([&](auto ic) __attribute__((always_inline)) { early_exp(I0{}, I0{}, ic); early_add(I0{}, I0{}, ic); if constexpr (NS == 2) { early_exp(I1{}, I0{}, ic); early_add(I1{}, I0{}, ic); } });
     }
     if constexpr (DIAG & 4) pt[5] = stamp() - k_t0;      // prologue: setup, first tiles landed, A(0), early(0)
     int t = 0;
@@ -1300,9 +1298,10 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
   int ovf = 0;
   if (wave_on && total_tiles > 0) {
-    const bool bad0 = !(st[0].l > 5.4e-20f && st[0].l < 1.8e19f), bad1 = !(st[1].l > 5.4e-20f && st[1].l < 1.8e19f);     // 2^-64 .. 2^64, NaN is bad
-    const bool on0 = qbase + wid * 64 + fr < p.S, on1 = qbase + wid * 64 + 32 + fr < p.S;
-    ovf = __any((bad0 && on0) || (bad1 && on1)) ? 1 : 0;
+    const bool bad0 = !(st[0].l > 5.4e-20f && st[0].l < 1.8e19f), on0 = qbase + wid * WQ + fr < p.S;     // 2^-64 .. 2^64, NaN is bad
+    bool bad = bad0 && on0;
+    if constexpr (NS == 2) bad = bad || (!(st[1].l > 5.4e-20f && st[1].l < 1.8e19f) && qbase + wid * WQ + 32 + fr < p.S);
+    ovf = __any(bad) ? 1 : 0;
     if constexpr (DIAG & 3) ovf = 0;          // timing builds: no second pass
   }
   if (lane == 0) wflags[wid] = ovf;
@@ -1310,12 +1309,12 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   if (tid == 0 && p.redo) p.redo[((long)row * gridDim.y + head) * p.redo_nb + blockIdx.x] = wflags[0] | wflags[1] | wflags[2] | wflags[3];
   if (!wave_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // no LDS-DMA may be in flight when a wave ends
   if (total_tiles == 0) load_gate(I0{});
-  load_gate(I1{});                 // stream 1's gate values: their latency is covered by stream 0's rows
+  if constexpr (NS == 2) load_gate(I1{});                 // stream 1's gate values: their latency is covered by stream 0's rows
 
   // ---- epilogue: lane holds O[q = 32 qb + fr][32 d + 8 g + 4 fh + 0..3]; gate values requested as one batch per query stream
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int q = qbase + wid * 64 + qb * 32 + fr;
+  for (int qb = 0; qb < NS; ++qb) {
+    const int q = qbase + wid * WQ + qb * 32 + fr;
     if (q >= p.S) continue;
     const bool gp = p.G != nullptr;
     const float inv_l = 1.0f / st[qb].l;
@@ -1346,6 +1345,12 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
   }
 }
 
+template <int DIAG>
+__global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
+  if (p.S - (int)blockIdx.x * 256 <= 128) attn5_body<DIAG, 1>(p);     // the short last block
+  else attn5_body<DIAG, 2>(p);
+}
+
 }  // namespace
 
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
@@ -1373,11 +1378,9 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
-    // A last block of at most 128 queries (S = 640: queries 512..639) would leave two of a 256-query workgroup's four waves idle: it goes to
-    // attn_kernel (128 queries per workgroup) in a second launch.  24 rows x 16 heads: 768 fast workgroups = three full rounds of the chip.
+    // (a last block of at most 128 queries runs the kernel's one-stream body: S = 640 is two 256-query workgroups + one of 128)
     const int nb256 = (a.S + 255) / 256;
-    const int rem = a.S - (nb256 - 1) * 256;
-    const int nfast = (variant == 5 && diag == 0 && nb256 > 1 && rem <= 128) ? nb256 - 1 : nb256;
+    const int nfast = nb256;
     AttnArgs f = a;
     f.redo_nb = nb256;
     f.q_block0 = 0;

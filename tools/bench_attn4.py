@@ -59,6 +59,13 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
         torch.cuda.synchronize()
         d.prof = None
         raw = prof.cpu()
+        nb = (S + 255) // 256
+        blk = (torch.arange(raw.shape[0]) // 4) % nb
+        for bsel in range(nb):
+            rb = raw[(blk == bsel) & (raw[:, 3] > 0)]
+            if rb.shape[0]:
+                x = rb[:, 7]
+                print("   block %d of a (row, head): %d waves, loop start %.0f | loop end %.0f | wave end %.0f cycles, steps %.1f" % (bsel, rb.shape[0], (x & 0xFFFFFFFF).double().mean(), (x >> 32).double().mean(), rb[:, 5].double().mean(), (rb[:, 3] & ((1 << 40) - 1)).double().mean()))
         raw = raw[raw[:, 3] > 0]
         pa, pb, pc = (raw[:, 1] >> 40).double().mean(), (raw[:, 2] >> 40).double().mean(), (raw[:, 4] >> 40).double().mean()
         pr = (raw & ((1 << 40) - 1)).double()
