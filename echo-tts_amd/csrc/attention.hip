@@ -1317,6 +1317,9 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
     const int q = qbase + wid * WQ + qb * 32 + fr;
     if (q >= p.S) continue;
     const bool gp = p.G != nullptr;
+    // every LDS-DMA piece of the last steps (tiles past the end) has landed before the first store is issued - the gate values, requested
+    // after them, are needed here anyway - so nothing is waited for at the kernel's end (a vmcnt(0) there also waits for the stores)
+    if (qb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float inv_l = 1.0f / st[qb].l;
     bf16_t* op = p.O + (long)row * p.o_row_stride + (long)q * p.o_ld + head * HD + 4 * fh;
 #pragma unroll
@@ -1335,8 +1338,8 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
         *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
       }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last steps' LDS-DMA (tiles past the end) must not outlive the workgroup's LDS
   if constexpr (DIAG & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
       unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
       dst[0] = pt[0]; dst[1] = pt[1] | (pa << 40); dst[2] = pt[2] | (pb << 40); dst[3] = pt[3]; dst[4] = pt[4] | (pc2 << 40);
