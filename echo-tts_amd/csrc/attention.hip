@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
 // one v_add each per step.  No LGKM drain at a step's end: the eight look-ahead reads stay in flight across the barrier.
 // The last step computes a dummy A(T) on whatever the K ring holds (a separate last-step path made hipcc spill): 32 MFMAs per workgroup.
 constexpr int K5_SLOTS = 4, V5_SLOTS = 3;
-constexpr int SMEM5 = K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16;
+constexpr int SMEM5 = K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16 + 4 * 32;      // rings | 4 range flags | segment table
 
 __device__ __forceinline__ bf16x8 lds_read16a(unsigned addr, int off) {      // LDS -> accumulator file
   bf16x8 v;
@@ -969,7 +969,10 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   auto NK = [&](int s) __attribute__((always_inline)) -> int { return s == 0 ? nk0 : s == 1 ? nk1 : s == 2 ? nk2 : s == 3 ? nk3 : 0; };
   auto NT = [&](int s) __attribute__((always_inline)) -> int { return (NK(s) + KT - 1) / KT; };
   const int total_tiles = NT(0) + NT(1) + NT(2) + NT(3);
-  const char* kb_[4]; const char* vb_[4]; int kld_[4], vld_[4];
+  // per-segment operands: resolved once, parked in LDS (segtab) and fetched by the rare paths of the tile walk (a segment switch, a ragged
+  // tile) - kept in scalar registers they (24 of ~100) pushed the walk's own state into VGPR lanes (95 v_readlane in the kernel)
+  struct SegEnt { const char* kb; const char* vb; int kld, vld, pad0, pad1; };      // 32 bytes
+  SegEnt* const segtab = (SegEnt*)(smem + K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16);
   int mod0 = 0;
 #pragma unroll
   for (int sgi = 0; sgi < 4; ++sgi)
@@ -977,21 +980,35 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   const int rmod0 = mod0 > 0 ? row % mod0 : row;
 #pragma unroll
   for (int sgi = 0; sgi < 4; ++sgi) {
-    kb_[sgi] = nullptr; vb_[sgi] = nullptr; kld_[sgi] = 0; vld_[sgi] = 0;
-    if (sgi < p.nseg) {
+    if (sgi < p.nseg && tid == 0) {
       const AttnSeg& sg = p.seg[sgi];
       const int kvrow = sg.kv_mod == 0 ? row : (sg.kv_mod == mod0 ? rmod0 : row % sg.kv_mod);
-      kb_[sgi] = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
-      vb_[sgi] = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
-      kld_[sgi] = (int)sg.k_ld * 2; vld_[sgi] = (int)sg.vt_ld * 2;
+      segtab[sgi].kb = (const char*)(sg.K + (long)kvrow * sg.k_row_stride + (long)head * sg.k_head_stride);
+      segtab[sgi].vb = (const char*)(sg.Vt + (long)kvrow * sg.vt_row_stride + (long)head * sg.vt_head_stride);
+      segtab[sgi].kld = (int)sg.k_ld * 2; segtab[sgi].vld = (int)sg.vt_ld * 2;
     }
   }
+  __syncthreads();
+  // one table entry into scalar registers (all LGKM traffic drained: the rare paths only)
+  typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+  struct SegVal { const char* kb; const char* vb; int kld, vld; };
+  auto seg_fetch = [&](int sg) __attribute__((always_inline)) -> SegVal {
+    const unsigned addr = (unsigned)(unsigned long)(lptr_t)segtab + (unsigned)sg * 32u;
+    u32x4t e0, e1;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e0), "=&v"(e1) : "v"(addr) : "memory");
+    SegVal r;
+    r.kb = (const char*)((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)e0[0]) | ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)e0[1]) << 32));
+    r.vb = (const char*)((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)e0[2]) | ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)e0[3]) << 32));
+    r.kld = __builtin_amdgcn_readfirstlane((int)e1[0]);
+    r.vld = __builtin_amdgcn_readfirstlane((int)e1[1]);
+    return r;
+  };
   auto next_seg = [&](int sg) __attribute__((always_inline)) -> int { ++sg; while (sg < 4 && NK(sg) == 0) ++sg; return sg; };
 
   // ---- the tile walk: w = tile t + 4 (its K is staged during step t), x3 = tile t + 3, x2 = tile t + 2 (its V^T is staged during step
   // t), valid1 = key count of tile t + 1 (masks the first softmax half).  Only w is advanced; the others are last step's w, x3, x2.  DMA roles as in attn4_kernel;
   // the per-lane role constants are recomputed where an offset changes (segment switch, ragged tile) instead of being kept in registers.
-  struct Tile { int seg, k0, nk; const char* kptr; const char* vptr; int kstep; };
+  struct Tile { int seg, k0, nk; const char* kptr; const char* vptr; int kstep; };      // kstep = the segment's K row pitch x KT
   struct Lag { int seg, valid; const char* vptr; };      // what the two followers need of a tile
   Tile w;
   Lag x3, x2;
@@ -1000,7 +1017,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   int vseg = -1;
   unsigned k_off[4], v_off[4];
   auto k_offsets = [&]() __attribute__((always_inline)) {
-    const int kld = SEL4(kld_, w.seg), last = w.nk - 1 - w.k0;        // rows past the segment's last key repeat it (masked in the softmax)
+    const int kld = w.kstep / KT, last = w.nk - 1 - w.k0;        // rows past the segment's last key repeat it (masked in the softmax)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (wid * 4 + i) * 4 + (lane >> 4);
@@ -1008,7 +1025,8 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
     }
   };
   auto enter = [&](int sg) __attribute__((always_inline)) {
-    w.seg = sg; w.k0 = 0; w.nk = NK(sg); w.kptr = SEL4(kb_, sg); w.vptr = SEL4(vb_, sg); w.kstep = SEL4(kld_, sg) * KT;
+    const SegVal e = seg_fetch(sg);
+    w.seg = sg; w.k0 = 0; w.nk = NK(sg); w.kptr = e.kb; w.vptr = e.vb; w.kstep = e.kld * KT;
     k_offsets();
   };
   auto advance = [&]() __attribute__((always_inline)) {                         // past the end the walk stays on the last tile
@@ -1019,7 +1037,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   auto v_offsets = [&]() __attribute__((always_inline)) {                       // per-lane offsets of the V^T pieces of x2's segment
     if (__builtin_expect(x2.seg != vseg, 0)) {
       vseg = x2.seg;
-      const int vld = SEL4(vld_, x2.seg);
+      const int vld = seg_fetch(x2.seg).vld;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int d = (wid * 4 + i) * 8 + (lane >> 3);
