@@ -101,12 +101,18 @@ def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, f
     return E, models, dacs, pca, ids.to(device), tmask, spk, smask, state
 
 
+def _baseline_ops():
+    """The checker's ops (oracle/): imported here only, for the two reported BASELINE legs below - never on the measured path."""
+    from oracle import echo_ref as R
+    return R
+
+
 def cpu_baseline(threads: int, state, pca, ids, tmask, spk, smask):
     """The CPU oracle (plain PyTorch restatement of the reference: bf16 EchoDiT + fp32 DAC like the GPU run) on the host cores,
     on the REAL 24-layer model with the bench's own weights and inputs: text + speaker KV encode in full, one 3-row
     CFG forward and one 1-row forward at S = 640 (the two step kinds of the schedule, each measured once after a warm-up of the
     1-row kind), DAC decode of 64 of the 640 frames.  Whole-utterance time = encoders + 20 x t3 + 20 x t1 + decode x 10."""
-    from oracle import echo_ref as R
+    R = _baseline_ops()
     torch.set_num_threads(threads)
     cfg, dcfg = R.DiTConfig(), R.DacConfig()
     w = {k: v.to("cpu") for k, v in state["dit"].items()}
@@ -151,7 +157,7 @@ def eager_gpu_baseline(state, pca, ids, tmask, spk, smask, sampler_kw, device):
     """SURVEY.md 8d / BASELINE.md 4: the reference's own execution model on this GPU - the oracle's torch ops run eagerly
     through PyTorch-ROCm (bf16 EchoDiT sampler, fp32 DAC decode), one utterance end to end (C2 proper), same weights and inputs.
     The oracle is only ever the baseline here, never the product path."""
-    from oracle import echo_ref as R
+    R = _baseline_ops()
     cfg, dcfg = R.DiTConfig(), R.DacConfig()
     w, dw = state["dit"], state["dac"]
     pc = R.PCA(pca.pca_components.to(device), pca.pca_mean.to(device), float(pca.latent_scale))

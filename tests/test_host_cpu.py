@@ -55,10 +55,11 @@ def test_product_never_imports_the_oracle():
         if fn.endswith((".py", ".sh")):
             src = open(os.path.join(ROOT, "tools", fn), encoding="utf-8").read()
             assert "from oracle" not in src and "import oracle" not in src, f"tools/{fn} imports the oracle"
-    # bench.py may use it in the cpu_baseline leg only: a single import site, inside cpu_baseline()
+    # bench.py may use it in its two reported baseline legs only (cpu_baseline, eager_gpu_baseline): a single import site, _baseline_ops()
     bsrc = open(os.path.join(ROOT, "bench.py"), encoding="utf-8").read()
     assert bsrc.count("from oracle") + bsrc.count("import oracle") == 1
-    assert bsrc.index("def cpu_baseline") < bsrc.index("from oracle") < bsrc.index("def host_threads")
+    assert bsrc.index("def _baseline_ops") < bsrc.index("from oracle") < bsrc.index("def cpu_baseline")
+    assert bsrc.count("_baseline_ops()") == 3          # its definition and the two baseline legs
 
 
 def test_tokenizer_and_masks_kat(golden):
