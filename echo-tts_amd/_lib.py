@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -71,7 +71,7 @@ class EchoGemmDesc(C.Structure):
                 ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int),
                 ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp),
                 ("qkv_mode", C.c_int), ("qkv_D", C.c_int), ("qkv_S", C.c_int), ("rope_heads", C.c_int), ("pos0", C.c_int), ("qk_eps", C.c_float),
-                ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64)]
+                ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64), ("w_presplit", C.c_int)]
 
 
 class EchoAttnSeg(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "echo_set_pca_encode": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, vp]),
     "echo_op_gemm": (C.c_int, [C.c_int, C.POINTER(EchoGemmDesc), vp]),
     "echo_op_quant_rows_fp8": (C.c_int, [vp, c_i64, vp, c_i64, vp, C.c_int, C.c_int, vp]),
+    "echo_op_presplit_weights": (C.c_int, [vp, c_i64, c_i64, vp]),
     "echo_op_pack_rows": (C.c_int, [vp, C.c_int, c_i64, vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_op_attention_bf16": (C.c_int, [C.POINTER(EchoAttnDesc), vp]),
     "echo_op_norm": (C.c_int, [C.c_int, C.c_int, vp, c_i64, vp, c_i64, C.c_int, C.c_int, C.c_float, vp, vp, vp]),

@@ -122,6 +122,7 @@ struct GemmArgs {
   int ksplit;                   // > 1: split K over blockIdx.z, fp32 partial slabs in ws, reduce kernel applies the tail
   void* ws; long ws_bytes;
   int split3;                   // fp32 only: bf16 hi/lo operand splitting, 3 bf16 MFMAs per product (gemm.hip SPLIT3)
+  int w_presplit;               // split3 only: W was reformatted by launch_presplit_w ([32 hi | 32 lo] bf16 per 32-float block)
   int pp_gn;                    // gemm_pp_kernel: tile columns per strip of the tile order (0 = default PP_GN)
   // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the
   // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
@@ -241,6 +242,7 @@ hipError_t launch_dwconv_ln(const float* x, long ldx, float* y, long ldy, int T,
 hipError_t launch_conv_out_tanh(const float* x, long ldx, float* y, long T, int S, int C, int k, const float* w /*(k,C)*/,
                                 float bias, hipStream_t st);
 hipError_t launch_pca_prep(const float* lat, float* out, long ldo, long rows, int L, int Lpad, float scale, hipStream_t st);
+hipError_t launch_presplit_w(float* w, long rows, long ld, hipStream_t st);
 hipError_t launch_snake_f32(const float* x, long ldx, float* y, long ldy, long rows, int C, const float* alpha, hipStream_t st);
 // encode path
 hipError_t launch_conv_in_snake(const float* x, long T, int C, int k, const float* w /*(C,k)*/, const float* b, const float* alpha,

@@ -1385,6 +1385,17 @@ struct Engine : EngineBase {
     pca_kpad = (int)rup(cfg.latent_size, 32);
     CK(alloc_zero((void**)&pca_w, (size_t)rup(C, 128) * pca_kpad * sizeof(float)));
     CK(alloc_zero((void**)&pca_b, (size_t)rup(C, 4) * sizeof(float)));
+    // the decoder's conv weights in the SPLIT3 kernels' pre-split format (gemm.hip, GemmArgs.w_presplit): they are GEMM W operands only
+    if (dac_split3) {
+      CK(launch_presplit_w(dconv0_w, rup(cfg.dac_decoder_dim, 128), 7L * C, st));
+      for (auto& Bk : dblocks) {
+        CK(launch_presplit_w(Bk.wt, rup(Bk.r * Bk.co, 128), 2L * Bk.ci, st));
+        for (auto& ru : Bk.ru) {
+          CK(launch_presplit_w(ru.w7, rup(Bk.co, 128), 7L * Bk.co, st));
+          CK(launch_presplit_w(ru.w1, rup(Bk.co, 128), Bk.co, st));
+        }
+      }
+    }
     CK(hipStreamSynchronize(st));
     drop_raw({"quantizer.", "decoder."});
     dac_ready = true;
@@ -1784,6 +1795,7 @@ struct Engine : EngineBase {
       // conv k7 C -> ch, epilogue writes only snake_{block1}(y)
       const int ch = cfg.dac_decoder_dim;
       GemmArgs g = FG(cur, C, dconv0_w, 7L * C, Y, ch, rows, ch, C);
+      g.w_presplit = dac_split3;
       g.taps = 7; g.tap_base = -6; g.tap_shift = 1; g.bias = dconv0_b;
       g.store_main = 0; g.C2 = S; g.snake_alpha = dblocks[0].alpha;
       CKI(frun(g, st));
@@ -1794,6 +1806,7 @@ struct Engine : EngineBase {
       {
         // ConvTranspose k=2r s=r as a 2-tap GEMM with N = r*Co; rows of C are r consecutive output steps
         GemmArgs g = FG(S, Bk.ci, Bk.wt, 2L * Bk.ci, Y, (long)Bk.r * Bk.co, rows, Bk.r * Bk.co, Bk.ci);
+        g.w_presplit = dac_split3;
         g.taps = 2; g.tap_base = -1; g.tap_shift = 1; g.bias = Bk.bt; g.vec_mod = Bk.co;
         g.C2 = Uu; g.snake_alpha = Bk.ru[0].a0;
         CKI(frun(g, st));
@@ -1805,6 +1818,7 @@ struct Engine : EngineBase {
         DacRU& ru = Bk.ru[j];
         {
           GemmArgs g = FG(S, Bk.co, ru.w7, 7L * Bk.co, Uu, Bk.co, rows, Bk.co, Bk.co);
+          g.w_presplit = dac_split3;
           g.taps = 7; g.tap_base = -6 * dil[j]; g.tap_shift = dil[j]; g.bias = ru.b7;
           g.store_main = 0; g.C2 = Uu; g.snake_alpha = ru.a1;
           CKI(frun(g, st));
@@ -1812,6 +1826,7 @@ struct Engine : EngineBase {
         {
           const float* next_alpha = j < 2 ? Bk.ru[j + 1].a0 : (bi + 1 < dblocks.size() ? dblocks[bi + 1].alpha : dfinal_alpha);
           GemmArgs g = FG(Uu, Bk.co, ru.w1, Bk.co, Y, Bk.co, rows, Bk.co, Bk.co);
+          g.w_presplit = dac_split3;
           g.bias = ru.b1; g.res = Y; g.ldres = Bk.co;
           g.store_main = j < 2 ? 1 : 0; g.C2 = S; g.snake_alpha = next_alpha;
           CKI(frun(g, st));
@@ -2013,11 +2028,14 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.bias = d->bias; g.bias_bo = d->bias_bo; g.bias_bi = d->bias_bi; g.vec_mod = d->vec_mod; g.div = d->div; g.act = d->act;
   g.colscale = d->colscale; g.res = d->res; g.ldres = d->ldres; g.res_bo = d->res_bo; g.res_bi = d->res_bi;
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
-  g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3;
+  g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3; g.w_presplit = d->split3 ? d->w_presplit : 0;
   g.fp8 = d->fp8; g.a_scale = d->a_scale; g.w_scale = d->w_scale;
   g.qkv_mode = d->qkv_mode; g.qkv_D = d->qkv_D; g.qkv_S = d->qkv_S; g.rope_heads = d->rope_heads; g.pos0 = d->pos0; g.qk_eps = d->qk_eps;
   g.qk_w = d->qk_w; g.rope = d->rope; g.vt = d->vt; g.vt_ld = d->vt_ld; g.vt_row_stride = d->vt_row_stride;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
+}
+int echo_op_presplit_weights(float* w, int64_t rows, int64_t ld, void* stream) {
+  return op_status(launch_presplit_w(w, rows, ld, (hipStream_t)stream));
 }
 int echo_op_pack_rows(const void* src, int sdt, int64_t sld, void* dst, int ddt, int64_t dld, int rows, int cols, int dst_row0,
                       int swiglu_half, void* stream) {

@@ -400,6 +400,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
     if (issued < nk) { stage(s); ++issued; }
 
   constexpr int NMF = (Num<T>::is_bf16 ? 4 : 16) * TN * TM;   // MFMAs per K step and wave
+  // the K loop exists twice in the SPLIT3 kernels: with W split in registers, and with W pre-split by the host side into [32 hi | 32 lo]
+  // bf16 per 32-float block (GemmArgs.w_presplit: static weights; the split of a weight fragment is 24 VALU instructions that every
+  // wave of every row tile repeated - the 128x96 tile spent 96 VALU per 9 MFMAs on it)
+  auto kloop = [&](auto wpre_) __attribute__((always_inline)) {
+  constexpr bool WPRE = decltype(wpre_)::value;
   for (int it = 0; it < nk; ++it) {
     // tile `it` must have landed: allow (tiles still in flight - 1) * PPW younger DMA pieces to stay outstanding
     const int younger = issued - it - 1;
@@ -466,7 +471,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 whi[TN], wlo[TN], ahi[TM], alo[TM];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) split(sa + w_row0 + t * 32 * KBYTES, kk, whi[t], wlo[t]);
+        for (int t = 0; t < TN; ++t) {
+          if constexpr (WPRE) {      // the block holds bf16 hi[0..31] | lo[0..31]: chunks 0-3 | 4-7 of 16 bytes, same swizzle
+            const char* rowp = sa + w_row0 + t * 32 * KBYTES;
+            whi[t] = *(const bf16x8*)(rowp + (((2 * kk + fh) ^ sw) << 4));
+            wlo[t] = *(const bf16x8*)(rowp + (((4 + 2 * kk + fh) ^ sw) << 4));
+          } else split(sa + w_row0 + t * 32 * KBYTES, kk, whi[t], wlo[t]);
+        }
 #pragma unroll
         for (int t = 0; t < TM; ++t) split(sa + a_row0 + t * 32 * KBYTES, kk, ahi[t], alo[t]);
 #pragma unroll
@@ -506,6 +517,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
       }
     }
   }
+  };
+  if constexpr (SPLIT3) { if (p.w_presplit) kloop(std::true_type{}); else kloop(std::false_type{}); }
+  else kloop(std::false_type{});
 
   // ---- epilogue (gemm_epilogue): this wave's accumulators of one 32-row pass go into the LDS slab
   const int fr_ = fr, fh_ = fh;
@@ -1349,3 +1363,29 @@ hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
 }
 template hipError_t launch_gemm_nt<bf16_t>(const GemmArgs&, hipStream_t);
 template hipError_t launch_gemm_nt<float>(const GemmArgs&, hipStream_t);
+
+// In-place reformat of an fp32 weight matrix [rows][ld] (ld % 32 == 0) for GemmArgs.w_presplit: every aligned block of 32 floats
+// becomes 32 bf16 hi = bf16(x) followed by 32 bf16 lo = bf16(x - hi) - the values the SPLIT3 kernels compute in registers.
+__global__ void presplit_w_kernel(float* __restrict__ w, long nblocks) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  float* blk = w + b * 32;
+  f32x8 x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = *(const f32x8*)(blk + 8 * i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const hbf16x8 h = __builtin_convertvector(x[i], hbf16x8);
+    const f32x8 hf = __builtin_convertvector(h, f32x8);
+    const hbf16x8 l = __builtin_convertvector(x[i] - hf, hbf16x8);
+    *(bf16x8*)((char*)blk + 16 * i) = __builtin_bit_cast(bf16x8, h);
+    *(bf16x8*)((char*)blk + 64 + 16 * i) = __builtin_bit_cast(bf16x8, l);
+  }
+}
+hipError_t launch_presplit_w(float* w, long rows, long ld, hipStream_t st) {
+  if (!w || rows < 1 || ld < 32 || (ld & 31)) return hipErrorInvalidValue;
+  const long nb = rows * (ld / 32);
+  hipLaunchKernelGGL(presplit_w_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, w, nb);
+  return hipGetLastError();
+}
+

@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 4
+#define ECHO_ABI_VERSION 5
 
 typedef struct echo_ctx echo_ctx;
 
@@ -186,8 +186,13 @@ typedef struct {
    * vt_row_stride in elements); gate is stored as is.  cfg 0-5 only, qkv_D % 256 == 0. */
   int qkv_mode, qkv_D, qkv_S, rope_heads, pos0; float qk_eps;
   const void* qk_w; const void* rope; void* vt; int64_t vt_ld, vt_row_stride;
+  int w_presplit;                /* split3 only: W was reformatted in place by echo_op_presplit_weights (static weights) */
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
+/* In-place reformat of an fp32 weight matrix (rows x ld, ld % 32 == 0) for w_presplit: every aligned block of 32 floats becomes
+ * 32 bf16 hi = bf16(x) followed by 32 bf16 lo = bf16(x - hi), the values the split3 kernels otherwise compute per fragment.  Results of a
+ * split3 GEMM are bit-identical with and without it.  (New in ABI 5; the engine applies it to the Fish S1-DAC decoder's conv weights.) */
+int echo_op_presplit_weights(float* w, int64_t rows, int64_t ld, void* stream);
 /* bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (amax / 448): the operand format of the fp8 GEMM */
 int echo_op_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream);
 int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,

@@ -38,7 +38,7 @@ def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
 def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
          nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
          vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
-         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None, qkv=None):
+         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None, qkv=None, w_presplit=0):
     d = L.EchoGemmDesc()
     es = A.element_size()
     d.A = A.data_ptr() + a_offset_elems * es
@@ -56,7 +56,7 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     d.res, d.ldres, d.res_bo, d.res_bi = ptr(res), ldres, res_bo, res_bi
     d.snake_alpha = ptr(snake_alpha)
     d.store_main, d.swiglu = store_main, swiglu
-    d.cfg, d.ksplit, d.split3 = cfg, ksplit, split3
+    d.cfg, d.ksplit, d.split3, d.w_presplit = cfg, ksplit, split3, w_presplit
     if a_scale is not None:   # e4m3 operands: A / W are uint8 tensors, the output C decides the dtype code
         d.fp8, d.a_scale, d.w_scale = 1, a_scale.data_ptr(), w_scale.data_ptr()
     if qkv is not None:       # fused QKV(G) tail: dict(D, S, rope_heads, pos0, eps, qk_w, rope, vt, vt_ld, vt_row_stride)

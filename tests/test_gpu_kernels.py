@@ -561,6 +561,33 @@ def test_gemm_f32_split3_accuracy(cfg):
     assert rel < 3e-5, rel
 
 
+@pytest.mark.parametrize("cfg,taps", [(0, 1), (2, 7), (4, 1), (6, 7), (7, 7), (8, 7), (9, 1), (8, 2)])
+def test_gemm_f32_split3_presplit_weights_bit_identical(cfg, taps):
+    """echo_op_presplit_weights + w_presplit: the weight operand of a split3 GEMM reformatted once ([32 hi | 32 lo] bf16 per 32-float
+    block) instead of being split per fragment by every wave.  Same hi / lo values, same MFMAs: bit-identical results, with taps
+    (the DAC decoder's causal dilated convs), ragged M, and N below the tile width."""
+    M, N, K = 333, 192, 96 * 2
+    rows = M + 8 * taps
+    A = rnd(rows, K)
+    W = U.pad_rows(rnd(N, taps * K, seed=1))
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=taps * K, ldc=N, cfg=cfg, split3=1, taps=taps, tap_base=-(taps - 1), tap_shift=1, a_offset_elems=(taps - 1) * K)
+    ref = torch.zeros((M, N), device=DEV)
+    U.gemm(A, W, ref, **kw)
+    Wp = W.clone()
+    L.check(U.lib().echo_op_presplit_weights(Wp.data_ptr(), Wp.shape[0], Wp.shape[1], U.stream()))
+    out = torch.zeros((M, N), device=DEV)
+    U.gemm(A, Wp, out, w_presplit=1, **kw)
+    torch.cuda.synchronize()
+    assert not torch.equal(Wp, W)
+    assert torch.equal(out, ref)
+    # and it is the fp32 product to split3 accuracy
+    acc = torch.zeros((M, N), dtype=torch.float64, device=DEV)
+    for t in range(taps):
+        acc += A[t:t + M].double() @ W[:N, t * K:(t + 1) * K].double().T
+    rel = ((out.double() - acc).pow(2).mean().sqrt() / acc.pow(2).mean().sqrt()).item()
+    assert rel < 3e-5, rel
+
+
 @pytest.mark.parametrize("R", [3, 1])
 def test_attention_is_deterministic_at_full_size(R):
     """Same launch three times at the C2 shape (S=640, 16 heads, 436 text + 640 speaker keys): bit-identical and finite.
