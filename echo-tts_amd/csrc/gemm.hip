@@ -181,6 +181,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
   // DRAIN: the slab reuses the staging buffers, so every LDS-DMA of the main loop must have landed first
   if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0);
   TailCols tcols;   // per-column tail operands of this thread's chunk (generic branch), read in the first pass
+  // generic branch: every thread keeps ONE 4-column chunk for the whole tile (threads beyond the last full row of chunks idle), so the
+  // per-column operands are read once per tile; rows advance by NT / CPR per step.  The residual rows of pass p + 1 are requested
+  // while pass p is processed: requested inside their own pass, the first load of every pass sat exposed behind the pass's two
+  // barriers (the DAC's 1-tap conv + residual launches: four ~2 us round trips per 128-row tile of a kernel with three K steps).
+  constexpr int RPS = NT / CPR, NTA = RPS * CPR, ITER = (32 + RPS - 1) / RPS;
+  const int g_chunk = tid % CPR, g_r0 = tid / CPR;
+  const int g_n0 = tile_n * BN + g_chunk * 4;
+  const bool g_col_ok = tid < NTA && g_n0 < p.N;
+  const bool generic = !(p.ksplit > 1) && !SWIGLU && !p.qkv_mode;
+  float rs_next[ITER][4];
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs_next[k][i] = 0.f;
+  auto fetch_res = [&](int pass_) __attribute__((always_inline)) {
+    const int mrow = tile_m * BM + pass_ * 32;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const int ml = g_r0 + k * RPS;
+      if (g_col_ok && ml < 32 && mrow + ml < p.M) gemm_tail_res<T>(p, mrow + ml, g_n0, zo, zi, rs_next[k]);
+    }
+  };
+  if (generic && p.res) fetch_res(0);
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     // raw barriers + lgkmcnt only: __syncthreads() would also wait (vmcnt) for the previous pass's global stores
@@ -278,27 +301,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         }
       }
     } else {
-      // every thread keeps ONE 4-column chunk for the whole tile (threads beyond the last full row of chunks idle), so the
-      // per-column operands are read once per tile; rows advance by NT / CPR per step and the residual of step k + 1 is
-      // requested before step k is stored
-      constexpr int RPS = NT / CPR, NTA = RPS * CPR, ITER = (32 + RPS - 1) / RPS;
-      const int chunk = tid % CPR, r0 = tid / CPR;
-      const int n0 = tile_n * BN + chunk * 4;
-      const bool col_ok = tid < NTA && n0 < p.N;
+      const int chunk = g_chunk, r0 = g_r0, n0 = g_n0;
+      const bool col_ok = g_col_ok;
       if (pass == 0 && col_ok) gemm_tail_cols<T>(p, n0, zo, zi, tcols);
-      float rs[2][4];
-      if (col_ok && r0 < 32 && mrow0 + r0 < p.M) gemm_tail_res<T>(p, mrow0 + r0, n0, zo, zi, rs[0]);
+      float rs[ITER][4];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[k][i] = rs_next[k][i];
+      if (p.res && pass + 1 < NPASS) fetch_res(pass + 1);
 #pragma unroll
       for (int k = 0; k < ITER; ++k) {
         const int ml = r0 + k * RPS, m = mrow0 + ml;
-        if (k + 1 < ITER) {
-          const int ml2 = ml + RPS;
-          if (col_ok && ml2 < 32 && mrow0 + ml2 < p.M) gemm_tail_res<T>(p, mrow0 + ml2, n0, zo, zi, rs[(k + 1) & 1]);
-        }
         if (col_ok && ml < 32 && m < p.M) {
           const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
           float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-          gemm_tail_apply<T>(p, m, n0, y, tcols, rs[k & 1], C, C2);
+          gemm_tail_apply<T>(p, m, n0, y, tcols, rs[k], C, C2);
         }
       }
     }
