@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   if (PROF) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
   // second pass behind attn4_kernel: only the 256-query blocks it flagged are done again here (with per-tile rescaling)
-  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.redo_nb + ((blockIdx.x + p.q_block0) >> 1)] == 0) return;
+  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.redo_nb + ((blockIdx.x + p.q_block0) >> (p.q128 ? 0 : 1))] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wid & 3, kh = wid >> 2;
@@ -927,11 +927,10 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t_end = 0;
   if constexpr (DIAG & 4) k_t0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [4][16 KiB] | V ring [3][16 KiB] | 4 range flags
-  constexpr int QW = 256;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = blockIdx.z, head = blockIdx.y;
-  const int qbase = blockIdx.x * QW;
+  const int qbase = blockIdx.x * (p.q128 ? 128 : 256);
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WQ = 32 * NS;                            // queries per wave
   const bool wave_on = qbase + wid * WQ < p.S;          // wave-uniform: a wave without queries only stages tiles
@@ -1368,7 +1367,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
 
 template <int DIAG>
 __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
-  if (p.S - (int)blockIdx.x * 256 <= 128) attn5_body<DIAG, 1>(p);     // the short last block
+  if (p.q128 || p.S - (int)blockIdx.x * 256 <= 128) attn5_body<DIAG, 1>(p);     // 128-query blocks (small grids), or the short last block
   else attn5_body<DIAG, 2>(p);
 }
 
@@ -1390,21 +1389,27 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
   // ECHO_ATTN=4 / 5 select attn4_kernel / attn5_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention, then attn_kernel
   // for the (normally zero) workgroups whose scores left the fast kernels' range; both launches on the caller's stream.
-  // Default: attn5_kernel when its grid fills the chip (>= 256 workgroups of 256 queries: from 6 rows x 16 heads x 640 queries on), else
-  // attn_kernel, whose two workgroups per CU hide the per-workgroup prologue / epilogue that attn5_kernel's single one exposes (measured,
-  // tools/bench_attn4.py, us: 24 rows 236 vs 268, 12 rows 132 vs 138, 8 rows 108 vs 114, 3 rows 54 vs 42).  ECHO_ATTN=1 / 4 / 5 force a kernel.
+  // Default: attn5_kernel - 256-query workgroups (two query streams per wave) when they fill the chip (>= 256 of them: from 6 rows x 16
+  // heads x 640 queries on), 128-query workgroups (one stream per wave, twice as many) below.  Measured (tools/bench_attn4.py, us, against
+  // attn_kernel): 24 rows 214-221 vs 268, 12 rows 123 vs 138, 8 rows 105 vs 113, 3 rows 40.5 vs 41.7, 1 row 34.4 vs 36.8.
+  // ECHO_ATTN=1 / 4 / 5 force a kernel, ECHO_ATTN_Q128=0 / 1 the block size.
   static const int forced = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : 0;
+  static const int forced_q128 = getenv("ECHO_ATTN_Q128") ? atoi(getenv("ECHO_ATTN_Q128")) : -1;
   const long wg5 = (long)((a.S + 255) / 256) * a.H * a.rows;
-  const int variant = forced ? forced : (wg5 >= 256 ? 5 : 1);
+  // below one full round of 256-query workgroups attn5_kernel runs 128-query blocks (one stream per wave): twice the workgroups
+  const bool q128 = forced_q128 >= 0 ? forced_q128 != 0 : wg5 < 256;
+  const int variant = forced ? forced : 5;
   if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
     // (a last block of at most 128 queries runs the kernel's one-stream body: S = 640 is two 256-query workgroups + one of 128)
-    const int nb256 = (a.S + 255) / 256;
+    const bool q128m = variant == 5 && q128;
+    const int nb256 = q128m ? (a.S + 127) / 128 : (a.S + 255) / 256;        // blocks of the fast kernel per (row, head)
     const int nfast = nb256;
     AttnArgs f = a;
     f.redo_nb = nb256;
     f.q_block0 = 0;
+    f.q128 = q128m ? 1 : 0;
     const dim3 g4(nfast, a.H, a.rows);
     if (variant == 4) {
       if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
@@ -1432,11 +1437,11 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     }
     b.q_block0 = 0;                              // second pass over the fast kernels' blocks: only the flagged ones do anything
     b.redo_filter = a.redo;
-    hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(min((int)grid.x, 2 * nfast), a.H, a.rows), dim3(512), SMEM, st, b);
+    hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(min((int)grid.x, q128m ? nfast : 2 * nfast), a.H, a.rows), dim3(512), SMEM, st, b);
     return hipGetLastError();
   }
   AttnArgs a0 = a;
-  a0.q_block0 = 0; a0.redo_nb = 0; a0.redo_filter = nullptr;
+  a0.q_block0 = 0; a0.redo_nb = 0; a0.redo_filter = nullptr; a0.q128 = 0;
   if (a.prof && !a.causal && !bias) hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, dim3(512), SMEM, st, a0);   // s_memtime stamps
   else if (a.causal && bias) hipLaunchKernelGGL((attn_kernel<true, true, false>), grid, dim3(512), SMEM, st, a0);
   else if (a.causal) hipLaunchKernelGGL((attn_kernel<true, false, false>), grid, dim3(512), SMEM, st, a0);

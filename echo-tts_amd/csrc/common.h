@@ -162,9 +162,10 @@ struct AttnArgs {
   int* redo;
   const int* redo_filter;       // set by the launcher on attn_kernel's second pass
   int q_block0;                 // set by the launcher: attn_kernel's first 128-query block (blockIdx.x counts from it)
-  int redo_nb;                  // set by the launcher: 256-query blocks per (row, head) in `redo`
+  int redo_nb;                  // set by the launcher: blocks per (row, head) in `redo`
+  int q128;                     // set by the launcher: attn5_kernel runs every block as 128 queries (one stream per wave), `redo` is per 128 queries
 };
-inline long attn_redo_words(int rows, int H, int S) { return (long)rows * H * ((S + 255) / 256); }
+inline long attn_redo_words(int rows, int H, int S) { return (long)rows * H * ((S + 127) / 128); }      // enough for the 128-query block mode
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)

@@ -77,7 +77,7 @@ def run(R, S=640, H=16, Lt=436, Ls=640, iters=30):
         print("   prologue: setup done %.0f | DMA issued %.0f | Q scaled %.0f" % (pa, pb, pc))
         print("   cycles per step incl. everything between the loop's first and last stamp: %.0f" % ((loop_end - pro) / n).mean())
         print("   per wave: setup + first tiles landed %.0f | + A(0), early(0) = loop start %.0f | loop end %.0f | wave end (O stored) %.0f cycles" % (pr[:, 6].mean(), pro.mean(), loop_end.mean(), pr[:, 5].mean()))
-    print(f"attn {('v' + os.environ['ECHO_ATTN']) if os.environ.get('ECHO_ATTN') else 'default (attn5_kernel from 256 workgroups on, else attn_kernel)'} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
+    print(f"attn {('v' + os.environ['ECHO_ATTN']) if os.environ.get('ECHO_ATTN') else 'default'} R={R:2d} S={S}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  finite={bool(torch.isfinite(out.float()).all())}", flush=True)
 
 
 if __name__ == "__main__":
