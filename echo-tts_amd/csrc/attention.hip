@@ -1313,7 +1313,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last PV MFMAs -> the epilogue's accumulator reads
   }
   // ---- range report: one word per workgroup, always written (launch_attention_bf16 runs attn_kernel for the flagged ones)
-  int ovf = 0;
+  int ovf = total_tiles > 0 ? 0 : 1;       // no key at all: left to attn_kernel
   if (wave_on && total_tiles > 0) {
     const bool bad0 = !(st[0].l > 5.4e-20f && st[0].l < 1.8e19f), on0 = qbase + wid * WQ + fr < p.S;     // 2^-64 .. 2^64, NaN is bad
     bool bad = bad0 && on0;
