@@ -865,8 +865,8 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
 // =====================================================================================================================================
 // attn5_kernel: 4 waves x 64 queries like attn4_kernel, but the two 32-query streams of a wave run in LOCKSTEP and share every LDS
 // fragment: one ds_read_b128 feeds two MFMAs (stream 0 and stream 1).  attn4_kernel (and attn_kernel) read one 1 KiB fragment per
-// MFMA: 4 waves x 1 KiB / 32 cycles = 128 B/clk/CU, the whole LDS bandwidth - its "no MFMA, no softmax" ablation build still takes
-// 120-147 us of the 250.  Here it is 64 B/clk.
+// MFMA - and a ds_read_b128 with four waves on the LDS port costs its wave ~19 issue cycles (tools/micro/mfma_fill.hip): attn4_kernel's
+// "no MFMA, no softmax" ablation build still takes 120-147 us of the 250.  Here it is one read per MFMA pair.
 //   step t:   A(t+1): S0,S1(t+1) = K(t+1) Q0^T, K(t+1) Q1^T   (16 K fragments, 32 MFMAs)  | late(t), both streams
 //             B(t):   O0,O1 += V^T(t) P0,P1(t)                 (16 V fragments, 32 MFMAs)  | early(t+1)
 // Scores are double-buffered in arch VGPRs (asm MFMAs in the VGPR form: 2 x 64 registers), P is packed into 32 more; O (128), Q (64)
@@ -881,6 +881,9 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
 // Ring slots are not literals (the loop is unrolled by two, for the score buffers): the eight K and four V^T read addresses move by
 // one v_add each per step.  No LGKM drain at a step's end: the eight look-ahead reads stay in flight across the barrier.
 // The last step computes a dummy A(T) on whatever the K ring holds (a separate last-step path made hipcc spill): 32 MFMAs per workgroup.
+// This wave's eight LDS-DMA pieces of a step go out in phase B (phase A carries the packing of P).  Workgroup shapes: 256 queries (two
+// streams per wave), or 128 queries with one stream per wave (NS = 1: a short last block, and every block of a grid of fewer than 256
+// workgroups, AttnArgs.q128).  The per-segment operands live in an LDS table (segtab) that only the walk's rare paths read.
 constexpr int K5_SLOTS = 4, V5_SLOTS = 3;
 constexpr int SMEM5 = K5_SLOTS * K_TILE_BYTES + V5_SLOTS * V_TILE_BYTES + 16 + 4 * 32;      // rings | 4 range flags | segment table
 
