@@ -1392,15 +1392,15 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   for (int s = 0; s < a.nseg; ++s) bias = bias || a.seg[s].bias != nullptr;
   // ECHO_ATTN=4 / 5 select attn4_kernel / attn5_kernel (4 waves x 64 queries, one wave per SIMD) for the joint attention, then attn_kernel
   // for the (normally zero) workgroups whose scores left the fast kernels' range; both launches on the caller's stream.
-  // Default: attn5_kernel - 256-query workgroups (two query streams per wave) when they fill the chip (>= 256 of them: from 6 rows x 16
-  // heads x 640 queries on), 128-query workgroups (one stream per wave, twice as many) below.  Measured (tools/bench_attn4.py, us, against
-  // attn_kernel): 24 rows 214-221 vs 268, 12 rows 123 vs 138, 8 rows 105 vs 113, 3 rows 40.5 vs 41.7, 1 row 34.4 vs 36.8.
-  // ECHO_ATTN=1 / 4 / 5 force a kernel, ECHO_ATTN_Q128=0 / 1 the block size.
+  // Default: attn5_kernel with 256-query workgroups (two query streams per wave), or 128-query ones for grids of at most one round (below).
+  // Measured (tools/bench_attn4.py, us, against attn_kernel): 24 rows 214-221 vs 268, 12 rows 123 vs 138, 8 rows 105 vs 113, 4 rows 53 vs 75,
+  // 3 rows 40.5 vs 41.7, 1 row 34.4 vs 36.8.  ECHO_ATTN=1 / 4 / 5 force a kernel, ECHO_ATTN_Q128=0 / 1 the block size.
   static const int forced = getenv("ECHO_ATTN") ? atoi(getenv("ECHO_ATTN")) : 0;
   static const int forced_q128 = getenv("ECHO_ATTN_Q128") ? atoi(getenv("ECHO_ATTN_Q128")) : -1;
-  const long wg5 = (long)((a.S + 255) / 256) * a.H * a.rows;
-  // below one full round of 256-query workgroups attn5_kernel runs 128-query blocks (one stream per wave): twice the workgroups
-  const bool q128 = forced_q128 >= 0 ? forced_q128 != 0 : wg5 < 256;
+  // 128-query workgroups (one stream per wave; 35 us each against 50) exactly when all of them run at once - one round of the chip.
+  // Measured (us, 128- vs 256-query blocks): 1 row 35 / 50, 3 rows 41 / 52, 4 rows 72 / 53, 6 rows 69 / 71, 8 rows 112 / 105, 24 rows 252 / 217
+  const long wg128 = (long)((a.S + 127) / 128) * a.H * a.rows;
+  const bool q128 = forced_q128 >= 0 ? forced_q128 != 0 : wg128 <= 256;
   const int variant = forced ? forced : 5;
   if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
