@@ -1011,12 +1011,12 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   // t), valid1 = key count of tile t + 1 (masks the first softmax half).  Only w is advanced; the others are last step's w, x3, x2.  DMA roles as in attn4_kernel;
   // the per-lane role constants are recomputed where an offset changes (segment switch, ragged tile) instead of being kept in registers.
   struct Tile { int seg, k0, nk; const char* kptr; const char* vptr; int kstep; };      // kstep = the segment's K row pitch x KT
-  struct Lag { int seg, valid; const char* vptr; };      // what the two followers need of a tile
+  struct Lag { int vld, valid; const char* vptr; };      // what the two followers need of a tile (vld: the segment's V^T row pitch in bytes)
   Tile w;
+  int w_vld = 0;
   Lag x3, x2;
   int valid1 = 0;
-  auto lag_of = [&]() __attribute__((always_inline)) -> Lag { return Lag{w.seg, w.nk - w.k0, w.vptr}; };
-  int vseg = -1;
+  auto lag_of = [&]() __attribute__((always_inline)) -> Lag { return Lag{w_vld, w.nk - w.k0, w.vptr}; };
   unsigned k_off[4], v_off[4];
   auto k_offsets = [&]() __attribute__((always_inline)) {
     const int kld = w.kstep / KT, last = w.nk - 1 - w.k0;        // rows past the segment's last key repeat it (masked in the softmax)
@@ -1028,7 +1028,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
   };
   auto enter = [&](int sg) __attribute__((always_inline)) {
     const SegVal e = seg_fetch(sg);
-    w.seg = sg; w.k0 = 0; w.nk = NK(sg); w.kptr = e.kb; w.vptr = e.vb; w.kstep = e.kld * KT;
+    w.seg = sg; w.k0 = 0; w.nk = NK(sg); w.kptr = e.kb; w.vptr = e.vb; w.kstep = e.kld * KT; w_vld = e.vld;
     k_offsets();
   };
   auto advance = [&]() __attribute__((always_inline)) {                         // past the end the walk stays on the last tile
@@ -1036,15 +1036,11 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
     else if (w.k0 + KT < w.nk) { w.k0 += KT; w.kptr += w.kstep; w.vptr += KT * 2; k_offsets(); }
     else { const int sg = next_seg(w.seg); if (sg < 4) enter(sg); }
   };
-  auto v_offsets = [&]() __attribute__((always_inline)) {                       // per-lane offsets of the V^T pieces of x2's segment
-    if (__builtin_expect(x2.seg != vseg, 0)) {
-      vseg = x2.seg;
-      const int vld = seg_fetch(x2.seg).vld;
+  auto v_offsets = [&]() __attribute__((always_inline)) {                       // per-lane offsets of the V^T pieces of x2's segment: four v_mad, no branch
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = (wid * 4 + i) * 8 + (lane >> 3);
-        v_off[i] = (unsigned)(d * vld + (((lane & 7) ^ ((d >> 1) & 7)) << 4));
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int d = (wid * 4 + i) * 8 + (lane >> 3);
+      v_off[i] = (unsigned)(d * x2.vld + (((lane & 7) ^ ((d >> 1) & 7)) << 4));
     }
   };
   auto dma_k = [&](int i, char* kdst) __attribute__((always_inline)) { glds16(w.kptr + k_off[i], kdst + i * 1024); };
@@ -1284,7 +1280,7 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
       if constexpr ((DIAG & 4) && !(DIAG & 128)) s1 = stamp();
       char* kdst = kring + kst * K_TILE_BYTES + wid * 4096;
       char* vdst = vring + (vst == 0 ? 2 : vst - 1) * V_TILE_BYTES + wid * 4096;
-      if (wave_on) {
+      if (__builtin_expect(wave_on, 1)) {
         ragged = valid1 < KT;
         mask_l = valid1 - 8 * fh;
         kdelta = kst == 2 ? -(K5_SLOTS - 1) * K_TILE_BYTES : K_TILE_BYTES;
