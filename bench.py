@@ -53,6 +53,7 @@ SAMPLER = dict(num_steps=STEPS, cfg_scale_text=3.0, cfg_scale_speaker=8.0, cfg_m
                sequence_length=S)
 AUDIO_S = S * 2048 / 44100.0
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+SUSTAINED_BF16_TFLOPS = 1770.0   # measured: pure MFMA issue, random bf16 operands, board power-limited (profiles/r02_mfma_power.log)
 
 
 PEAK_FP8_TFLOPS = 5000.0           # dense block-scaled fp8 MFMA (same guide): the --c5 line is priced against this
@@ -292,6 +293,11 @@ def main() -> None:
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches": pr.n_pp, "avg_launch_us": round(1e3 * pr.ms_pp_sum / max(pr.n_pp, 1), 2),
                     "flops_per_launch": pr.flops_pp / max(pr.n_pp, 1),
+                    "power_envelope": None if args.c5 else {
+                        "sustained_mfma_peak": SUSTAINED_BF16_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_BF16_TFLOPS, 4),
+                        "note": "v_mfma_f32_32x32x16_bf16 issued back to back from registers on every SIMD (no LDS, no memory) sustains 1770 TFLOP/s on "
+                                "random operands (board at its power limit, shader clock 1.7-1.8 GHz; 2484 on zeros): tools/micro/mfma_power.hip, "
+                                "profiles/r02_mfma_power.log; `peak`/`frac` above stay the dense 2.4 GHz figure of MI355X_MICROARCH.md"},
                     "all_linears": {"achieved": round(ach_all, 1), "launches": pr.n_gemm, "ms": round(pr.ms_gemm_sum, 2),
                                     "note": "every gemm launch of the call incl. the small ones (in/out projections, modulation tables), algorithmic FLOPs of SURVEY.md 8d"}}
         dac.set_profiling(True)
