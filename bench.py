@@ -204,7 +204,7 @@ def main() -> None:
     ap.add_argument("--concurrency", type=int, default=2,
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=24,
                     help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
     ap.add_argument("--c5", action="store_true",
                     help="BASELINE config C5 instead of C2: fp8 (e4m3) operands for the EchoDiT block GEMMs, 100 Euler steps "

@@ -9,7 +9,7 @@ mkdir -p $O
 PMC_CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-eager-baseline --no-roofline"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- $PMC_CMD > $O/pmc_fetch.log 2>&1
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- $PMC_CMD > $O/pmc_write.log 2>&1
-python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write profiles/r02_pmc_gemm.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- $PMC_CMD (two separate passes; default batch 8, 2 streams)"
+python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write profiles/r02_pmc_gemm.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- $PMC_CMD (two separate passes; default batch 24, 2 streams)"
 cp profiles/r02_pmc_gemm.json $O/r02_pmc_gemm.json
 rm -rf $O/pmc_fetch $O/pmc_write
 # 2. tests + smoke
@@ -29,5 +29,5 @@ head -c 200 $O/r02_bench_line_c5_$V.json; echo
 # 4. kernel trace of the same command (shorter run, no CPU leg)
 timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-baseline > $O/prof.log 2>&1
 rm -f $O/prof/*kernel_trace.csv $O/prof/*/*kernel_trace.csv
-python3 tools/summarize_prof.py $(ls $O/prof/*kernel_stats.csv $O/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $O/r02_bench_kernel_stats_$V.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-baseline (batch 8, 2 streams)"
+python3 tools/summarize_prof.py $(ls $O/prof/*kernel_stats.csv $O/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $O/r02_bench_kernel_stats_$V.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-baseline (batch 24, 2 streams)"
 tail -n 1 $O/prof.log | head -c 600
