@@ -64,3 +64,14 @@ A = torch.randn((M + 256, K), device="cuda").to(torch.bfloat16)
 W = (torch.randn((N, K), device="cuda") * 0.02).to(torch.bfloat16)
 run("random normal", A, W, M, N, K)
 run("random A, zero W", A, wz, M, N, K)
+
+# joint attention (attn5_kernel, 24 rows: the batch-8 CFG step's launch) under the same sampling
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_attn4", os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_attn4.py"))
+ba = importlib.util.module_from_spec(spec); spec.loader.exec_module(ba)
+stop, out = threading.Event(), []
+th = threading.Thread(target=sample, args=(stop, out))
+th.start()
+ba.run(24, iters=5000)
+stop.set(); th.join()
+print("attention 24 rows: power W", [r["power_w"] for r in out if "power_w" in r], "| sclk", [r["sclk"] for r in out if "sclk" in r], flush=True)
