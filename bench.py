@@ -209,6 +209,9 @@ def main() -> None:
     ap.add_argument("--c5", action="store_true",
                     help="BASELINE config C5 instead of C2: fp8 (e4m3) operands for the EchoDiT block GEMMs, 100 Euler steps "
                          "(50 CFG x3 rows + 50 x1 row); the JSON line then says dtype fp8 and names C5 in config.workload")
+    ap.add_argument("--c5-dynamic", action="store_true",
+                    help="with --c5: per-token-row activation scales for every operand (two quantisation passes per block) instead of the "
+                         "calibrated static scales for the attention / SwiGLU outputs")
     ap.add_argument("--dist-backend", default=None, help="testing only: e.g. gloo to rehearse N ranks on one GPU")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this cuda index")
     args = ap.parse_args()
@@ -230,6 +233,15 @@ def main() -> None:
     want_base = rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_eager_baseline)
     E, models, dacs, pca, ids, tmask, spk, smask, state = build(device, rank, world, conc, nb, fp8=args.c5, keep_state=want_base)
     model, dac = models[0], dacs[0]
+    c5_static = None
+    if args.c5 and not args.c5_dynamic:
+        # fp8 activation-scale calibration (outside the timed region; a deployment does it once per checkpoint and keeps the JSON of
+        # weights.save_fp8_scales): 10 Euler steps of the bench's own request on the dynamic path, maxima x 1.25
+        models[0].fp8_calibration_start()
+        E.sample_euler_cfg_independent_guidances(models[0], spk, smask, ids[:min(nb, 4)], tmask[:min(nb, 4)], rng_seed=11, **dict(sampler_kw, num_steps=10))
+        c5_static = models[0].fp8_calibration_finish(margin=1.25)
+        for m in models:
+            m.set_fp8_static_scales(c5_static)
     streams = [torch.cuda.Stream(device=device) for _ in range(conc)] if conc > 1 else [torch.cuda.current_stream(device)]
 
     last = {}
@@ -357,7 +369,9 @@ def main() -> None:
             "value": round(total_audio / dt, 3), "unit": "audio-s/s (whole job; divide by n_gpus for per-GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8 (e4m3 operands of the EchoDiT block GEMMs, fp32 accumulate; bf16 elsewhere, fp32 DAC)" if args.c5 else "bf16", "data": "synthetic",
+            "dtype": ("fp8 (e4m3 operands of the EchoDiT block GEMMs, fp32 accumulate; " + ("per-token-row activation scales" if c5_static is None else
+                      "calibrated static scales for the attention / SwiGLU outputs written by their producers, per-token-row scales elsewhere")
+                      + "; bf16 elsewhere, fp32 DAC)") if args.c5 else "bf16", "data": "synthetic",
             "per_gpu": round(total_audio / dt / world, 3),
             "config": {"workload": f"{'C5' if args.c5 else 'C2'}: {conc * nb} utterance(s)/step/GPU ({nb} per sampler call, {conc} HIP stream(s)), seq_len=640, "
                                    f"{n_steps} Euler steps ({n_steps // 2} CFG x3 rows + {n_steps - n_steps // 2} x1 row), "

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -71,7 +71,8 @@ class EchoGemmDesc(C.Structure):
                 ("cfg", C.c_int), ("ksplit", C.c_int), ("ws", vp), ("ws_bytes", c_i64), ("split3", C.c_int),
                 ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp),
                 ("qkv_mode", C.c_int), ("qkv_D", C.c_int), ("qkv_S", C.c_int), ("rope_heads", C.c_int), ("pos0", C.c_int), ("qk_eps", C.c_float),
-                ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64), ("w_presplit", C.c_int)]
+                ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64), ("w_presplit", C.c_int),
+                ("a_scale_const", C.c_float), ("c8", vp), ("c8_ld", c_i64), ("c8_inv", C.c_float)]
 
 
 class EchoAttnSeg(C.Structure):
@@ -85,7 +86,8 @@ class EchoAttnDesc(C.Structure):
                 ("O", vp), ("o_ld", c_i64), ("o_row_stride", c_i64),
                 ("G", vp), ("g_ld", c_i64), ("g_row_stride", c_i64),
                 ("S", C.c_int), ("H", C.c_int), ("rows", C.c_int), ("nseg", C.c_int),
-                ("seg", EchoAttnSeg * 4), ("causal", C.c_int), ("scale", C.c_float), ("prof", vp), ("redo", vp)]
+                ("seg", EchoAttnSeg * 4), ("causal", C.c_int), ("scale", C.c_float), ("prof", vp), ("redo", vp),
+                ("O8", vp), ("o8_ld", c_i64), ("o8_row_stride", c_i64), ("o8_inv", C.c_float)]
 
 
 class EchoProfile(C.Structure):
@@ -135,6 +137,9 @@ SIGNATURES = {
     "echo_voice_destroy": (None, [vp]),
     "echo_dac_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
     "echo_workspace_bytes": (c_i64, [vp]),
+    "echo_fp8_calibrate": (C.c_int, [vp, C.c_int]),
+    "echo_fp8_calibration": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int]),
+    "echo_fp8_set_static_scales": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int]),
     "echo_reserve_workspace": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "echo_op_find_flattening_point": (C.c_int, [vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
     "echo_op_trailing_quiet": (C.c_int, [C.POINTER(vp), C.POINTER(c_i64), C.c_int, C.c_int, C.c_float, vp, vp]),

@@ -55,6 +55,15 @@ struct Stream { int seg, k0, nk; const char* ptr; int step; };
 
 // Software-pipelined by one tile: the Sᵀ = K·Qᵀ MFMAs of tile t+1 are issued before the softmax (VALU) of tile t
 // so the two overlap inside one wave; K tiles therefore run one tile ahead of V tiles in the LDS rings.
+// fp8 engine with static activation scales (AttnArgs.O8): four outputs -> e4m3(bf16(y) * inv), saturating, one 32-bit store
+__device__ __forceinline__ void store_o4_fp8(uint8_t* dst, const float (&y)[4], float inv) {
+  float z[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) z[i] = __builtin_amdgcn_fmed3f(bf2f(f2bf(y[i])) * inv, -448.0f, 448.0f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(z[2], z[3], w, true);
+  *(int*)dst = w;
+}
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -426,7 +435,8 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
       }
-      *(uint2*)(op + col) = Vec4<bf16_t>::pack(y);
+      if (p.O8) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + col, y, p.o8_inv);
+      else *(uint2*)(op + col) = Vec4<bf16_t>::pack(y);
     }
 }
 
@@ -1351,7 +1361,8 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
         }
-        *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
+        if constexpr (DIAG & 256) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + 4 * fh + 32 * d + 8 * g, y, p.o8_inv);
+        else *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
       }
   }
   if constexpr (DIAG & 4) {
@@ -1375,6 +1386,7 @@ __global__ void __launch_bounds__(256, 1) attn5_kernel(const AttnArgs p) {
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   if (a.nseg < 1 || a.nseg > 4 || a.S < 1 || a.H < 1 || a.rows < 1) return hipErrorInvalidValue;
   if (a.causal && a.nseg != 1) return hipErrorInvalidValue;
+  if (a.O8 && (!(a.o8_inv > 0.0f) || (a.o8_ld & 3))) return hipErrorInvalidValue;
   for (int s = 0; s < a.nseg; ++s)
     if ((a.seg[s].vt_ld & 7) || (a.seg[s].k_ld & 7) || !a.seg[s].nkeys) return hipErrorInvalidValue;
   static std::atomic<unsigned long long> prepared[5];
@@ -1397,7 +1409,7 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
   // Measured (us, 128- vs 256-query blocks): 1 row 35 / 50, 3 rows 41 / 52, 4 rows 72 / 53, 6 rows 69 / 71, 8 rows 112 / 105, 24 rows 252 / 217
   const long wg128 = (long)((a.S + 127) / 128) * a.H * a.rows;
   const bool q128 = forced_q128 >= 0 ? forced_q128 != 0 : wg128 <= 256;
-  const int variant = forced ? forced : 5;
+  const int variant = forced && !(a.O8 && forced == 4) ? forced : 5;      // attn4_kernel has no e4m3 output
   if (!a.causal && !bias && (!a.prof || forced == 5) && (variant == 4 || variant == 5) && a.redo) {
     static std::atomic<unsigned long long> prep4[6];
     static const int diag = getenv("ECHO_ATTN_DIAG") ? atoi(getenv("ECHO_ATTN_DIAG")) : 0;      // timing experiments (tools/bench_attn4.py)
@@ -1410,7 +1422,11 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     f.q_block0 = 0;
     f.q128 = q128m ? 1 : 0;
     const dim3 g4(nfast, a.H, a.rows);
-    if (variant == 4) {
+    if (a.O8) {            // e4m3 output (fp8 engine, static activation scales): attn5_kernel<256>
+      static std::atomic<unsigned long long> prep8{0};
+      if (hipError_t e = ensure_dyn_lds((const void*)attn5_kernel<256>, SMEM5, prep8); e != hipSuccess) return e;
+      hipLaunchKernelGGL(attn5_kernel<256>, g4, dim3(256), SMEM5, st, f);
+    } else if (variant == 4) {
       if (hipError_t e = ensure_dyn_lds((const void*)attn4_kernel<0>, SMEM4, prep4[0]); e != hipSuccess) return e;
       hipLaunchKernelGGL(attn4_kernel<0>, g4, dim3(256), SMEM4, st, f);
     } else {

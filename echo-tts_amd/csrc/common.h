@@ -123,6 +123,11 @@ struct GemmArgs {
   void* ws; long ws_bytes;
   int split3;                   // fp32 only: bf16 hi/lo operand splitting, 3 bf16 MFMAs per product (gemm.hip SPLIT3)
   int w_presplit;               // split3 only: W was reformatted by launch_presplit_w ([32 hi | 32 lo] bf16 per 32-float block)
+  // fp8 operands with a static (calibrated) activation scale: a_scale == nullptr -> every A row has the scale a_scale_const;
+  // SwiGLU tail of the fp8 ping-pong kernel with c8 != nullptr: the output leaves as e4m3(bf16(out) * c8_inv) bytes at c8 (pitch c8_ld
+  // bytes) instead of bf16 at C - the A operand of w2 without a quantisation pass
+  float a_scale_const;
+  void* c8; long c8_ld; float c8_inv;
   int pp_gn;                    // gemm_pp_kernel: tile columns per strip of the tile order (0 = default PP_GN)
   // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the
   // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
@@ -163,7 +168,9 @@ struct AttnArgs {
   const int* redo_filter;       // set by the launcher on attn_kernel's second pass
   int q_block0;                 // set by the launcher: attn_kernel's first 128-query block (blockIdx.x counts from it)
   int redo_nb;                  // set by the launcher: blocks per (row, head) in `redo`
-  int q128;                     // set by the launcher: attn5_kernel runs every block as 128 queries (one stream per wave), `redo` is per 128 queries
+  int q128;                     // set by the launcher: attn5_kernel runs every block as 128 queries (one stream per wave), `redo` is per 128 queries  // fp8 engine with static (calibrated) activation scales: O8 != nullptr -> the epilogue writes e4m3(bf16(out) * o8_inv) bytes there
+  // (same indexing as O, pitches in bytes) INSTEAD of the bf16 output: the A operand of the wo GEMM without a quantisation pass
+  uint8_t* O8; long o8_ld, o8_row_stride; float o8_inv;
 };
 inline long attn_redo_words(int rows, int H, int S) { return (long)rows * H * ((S + 127) / 128); }      // enough for the 128-query block mode
 hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st);
@@ -189,6 +196,8 @@ template <typename T> hipError_t launch_embedding(const int* ids, const T* table
 template <typename T> hipError_t launch_silu(const T* x, T* y, long n, hipStream_t st);
 // bf16 rows -> OCP e4m3 bytes + per-row fp32 scale (amax / 448)
 hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st);
+// *dst = max(*dst, max_i v[i]) for non-negative finite v (fp8 calibration: the largest row scale a block has seen)
+hipError_t launch_max_into(const float* v, int n, float* dst, hipStream_t st);
 // bf16 AdaLN-apply norm (norm_kernel<bf16, NORM_ADALN>) whose output leaves as e4m3 bytes + per-row scale
 hipError_t launch_norm_adaln_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int D, float eps, const void* scale1p,
                                  const void* shift, hipStream_t st);

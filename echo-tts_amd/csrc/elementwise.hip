@@ -501,6 +501,20 @@ hipError_t launch_norm_adaln_fp8(const void* x, long ldx, void* q, long ldq, flo
                      rows, D, eps, (const bf16_t*)scale1p, (const bf16_t*)shift);
   return hipGetLastError();
 }
+__global__ void __launch_bounds__(256) max_into_kernel(const float* __restrict__ v, int n, float* dst) {
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, v[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)dst, __float_as_uint(m));
+}
+hipError_t launch_max_into(const float* v, int n, float* dst, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(max_into_kernel, dim3((unsigned)std::min((n + 255) / 256, 64)), dim3(256), 0, st, v, n, dst);
+  return hipGetLastError();
+}
+
 hipError_t launch_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int K, hipStream_t st) {
   if (rows < 1 || K < 8 || (K & 7) || (ldx & 7) || (ldq & 7)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale,

@@ -187,6 +187,9 @@ struct EngineBase {
   virtual int dac_decode_tail(const float* lat, int T, int f0, float scale, float* wav, hipStream_t st) = 0;
   virtual size_t workspace_bytes() = 0;
   virtual int reserve_workspace(int B, int S, int Tt, int Ts, int T_dac) = 0;
+  virtual int fp8_calibrate(int on) = 0;
+  virtual int fp8_calibration(float* out, int n) = 0;
+  virtual int fp8_set_static(const float* s, int n) = 0;
 };
 
 #define CK(x)                                            \
@@ -306,6 +309,13 @@ struct Engine : EngineBase {
   std::vector<uint8_t*> q_wqkvg, q_wo, q_w13, q_w2;     // e4m3 copies of the packed block weights
   std::vector<float*> s_wqkvg, s_wo, s_w13, s_w2;       // one scale per weight row
   DevBuf b_q8, b_qs;                                    // quantised A operand of the current GEMM + its row scales
+  // static (calibrated) activation scales for the two operands no producer can quantise per row - the attention output (wo's A) and the
+  // SwiGLU output (w2's A): [2 l] / [2 l + 1] = amax / 448 bounds per block.  With them the attention epilogue and the SwiGLU tail write
+  // e4m3 bytes themselves (AttnArgs.O8, GemmArgs.c8) and the two quant_rows_fp8 passes of a block disappear.  Calibration: the dynamic
+  // path's own row scales, max-reduced per block into b_calib while `calibrating` (echo_fp8_calibrate / echo_fp8_calibration).
+  std::vector<float> fp8_static;                        // empty = dynamic row scales everywhere
+  bool calibrating = false;
+  DevBuf b_calib, b_h8;                                 // 2 L floats (as ordered uint bits) | e4m3 SwiGLU output rows
   static bool fp8_shape_ok(long N, long K) { return K % 128 == 0 && N % 8 == 0; }
   int quant_weight(const T* w, long rows, long K, std::vector<uint8_t*>& qv, std::vector<float*>& sv, hipStream_t st) {
     uint8_t* q = nullptr; float* sc = nullptr;
@@ -324,11 +334,12 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
   // `quantised`: b_q8 / b_qs already hold the A rows (norm_adaln_fp8 wrote them)
-  int to_fp8(GemmArgs& g, const uint8_t* qw, const float* sw, hipStream_t st, bool quantised = false) {
+  int to_fp8(GemmArgs& g, const uint8_t* qw, const float* sw, hipStream_t st, bool quantised = false, int calib_slot = -1) {
     if (!fp8 || !qw) return ECHO_OK;
     if (!quantised) {
       CKI(fp8_reserve(g.M, g.K));
       CK(launch_quant_rows_fp8(g.A, g.lda, b_q8.p, g.K, b_qs.as<float>(), g.M, g.K, st));
+      if (calibrating && calib_slot >= 0) CK(launch_max_into(b_qs.as<float>(), g.M, b_calib.as<float>() + calib_slot, st));
     }
     g.A = b_q8.p; g.lda = g.K; g.W = qw; g.ldw = g.K; g.fp8 = 1; g.a_scale = b_qs.as<float>(); g.w_scale = sw;
     return ECHO_OK;
@@ -601,7 +612,7 @@ struct Engine : EngineBase {
   };
   // q/gate/out live in [rows*S][..] buffers with per-row stride S*ld
   int attention(const T* q, long q_ld, const T* gate, long g_ld, T* out, long o_ld, int rows, int S, int H, const SegDesc* segs,
-                int nseg, bool causal, hipStream_t st) {
+                int nseg, bool causal, hipStream_t st, uint8_t* out8 = nullptr, long o8_ld = 0, float o8_inv = 0.f) {
     const int* nk = b_nkeys.as<int>();
     if constexpr (Num<T>::is_bf16) {
       AttnArgs a;
@@ -609,6 +620,7 @@ struct Engine : EngineBase {
       a.Q = q; a.q_ld = q_ld; a.q_row_stride = (long)S * q_ld;
       a.O = out; a.o_ld = o_ld; a.o_row_stride = (long)S * o_ld;
       a.G = gate; a.g_ld = g_ld; a.g_row_stride = (long)S * g_ld;
+      a.O8 = out8; a.o8_ld = o8_ld; a.o8_row_stride = (long)S * o8_ld; a.o8_inv = o8_inv;
       a.S = S; a.H = H; a.rows = rows; a.causal = causal ? 1 : 0; a.scale = 1.0f / sqrtf(128.0f);
       int n = 0;
       for (int s = 0; s < nseg; ++s) {
@@ -972,9 +984,37 @@ struct Engine : EngineBase {
   }
 
   size_t workspace_bytes() override {
-    size_t n = b_gemm_ws.cap + b_tune_c.cap + b_flush.cap + b_q8.cap + b_qs.cap;
+    size_t n = b_gemm_ws.cap + b_tune_c.cap + b_flush.cap + b_q8.cap + b_qs.cap + b_h8.cap + b_calib.cap;
     for (DevBuf* b : all_bufs()) n += b->cap;
     return n;
+  }
+  // ---- fp8 activation-scale calibration (BASELINE C5).  fp8_calibrate(1) clears the per-block maxima and makes the dynamic
+  // path record them (static scales are ignored while it is on); fp8_calibration() returns the 2 L maxima seen so far (row scale =
+  // amax / 448: [2 l] attention output, [2 l + 1] SwiGLU output); fp8_set_static() installs 2 L scales (the caller applies its margin),
+  // n = 0 goes back to dynamic row scales.
+  int fp8_calibrate(int on) override {
+    if (!fp8) return fail("fp8 calibration needs an engine created with dit_fp8");
+    if (on) {
+      CK(b_calib.reserve((size_t)2 * cfg.num_layers * sizeof(float)));
+      CK(hipMemset(b_calib.p, 0, (size_t)2 * cfg.num_layers * sizeof(float)));
+    }
+    calibrating = on != 0;
+    return ECHO_OK;
+  }
+  int fp8_calibration(float* out, int n) override {
+    if (!fp8 || !b_calib.p || n != 2 * cfg.num_layers || !out) return fail("fp8_calibration: no calibration data / n != 2 * num_layers");
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, b_calib.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return ECHO_OK;
+  }
+  int fp8_set_static(const float* sc, int n) override {
+    if (!fp8) return fail("static fp8 scales need an engine created with dit_fp8");
+    if (n == 0) { fp8_static.clear(); return ECHO_OK; }
+    if (n != 2 * cfg.num_layers || !sc) return fail("fp8_set_static: n != 2 * num_layers");
+    for (int i = 0; i < n; ++i)
+      if (!(sc[i] > 0.0f) || !std::isfinite(sc[i])) return fail("fp8_set_static: scales must be positive and finite");
+    fp8_static.assign(sc, sc + n);
+    return ECHO_OK;
   }
   // grows every workspace a request of this geometry touches (B utterances per sampler call, S latents, Tt text tokens,
   // Ts speaker latents, T_dac frames per DAC decode), so that the first request allocates nothing (SURVEY.md §8b "ownership")
@@ -1110,11 +1150,21 @@ struct Engine : EngineBase {
         sg[3].Vt = b_vt_spk.as<T>() + (long)l * spkB * D * spk_vld; sg[3].vt_ld = spk_vld; sg[3].vt_row_stride = (long)D * spk_vld;
         if (spk_has_bias) { sg[3].bias = b_bias_spk.as<float>(); sg[3].bias_ld = spk_bias_ld; }
       }
-      CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st));
-      {
+      // static activation scales (fp8 engine, calibrated): the attention epilogue writes wo's e4m3 operand, the SwiGLU tail w2's
+      const bool st8 = fp8 && (int)fp8_static.size() == 2 * L && q_wo[l] != nullptr && q_w2[l] != nullptr && q_w13[l] != nullptr && !calibrating;
+      if (st8) {
+        CKI(fp8_reserve(M, std::max(D, F)));
+        CK(b_h8.reserve((size_t)(M + 256) * F));
+        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, b_q8.as<uint8_t>(), D, 1.0f / fp8_static[2 * l]));
         GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
         g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
-        if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st));
+        g.A = b_q8.p; g.lda = D; g.W = q_wo[l]; g.ldw = D; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l]; g.w_scale = s_wo[l];
+        CKI(run(g, st));
+      } else {
+        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st));
+        GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
+        g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
+        if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st, false, 2 * l));
         CKI(run(g, st));
       }
       if (nq2) {
@@ -1127,12 +1177,15 @@ struct Engine : EngineBase {
         GemmArgs g = G(xn, D, w13[l], D, hh, F, M, 2 * F, D);
         g.swiglu = 1;
         if (fp8) CKI(to_fp8(g, q_w13[l], s_w13[l], st, nq2));
+        if (st8 && g.fp8) { g.c8 = b_h8.p; g.c8_ld = F; g.c8_inv = 1.0f / fp8_static[2 * l + 1]; }
         CKI(run(g, st));
       }
       {
         GemmArgs g = G(hh, F, w2[l], F, x, D, M, D, F);
         g.colscale = mm + 2 * D; g.res = x; g.ldres = D;
-        if (fp8) CKI(to_fp8(g, q_w2[l], s_w2[l], st));
+        if (st8) {
+          g.A = b_h8.p; g.lda = F; g.W = q_w2[l]; g.ldw = F; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l + 1]; g.w_scale = s_w2[l];
+        } else if (fp8) CKI(to_fp8(g, q_w2[l], s_w2[l], st, false, 2 * l + 1));
         CKI(run(g, st));
       }
     }
@@ -2002,6 +2055,10 @@ int echo_reserve_workspace(echo_ctx* ctx, int B, int S, int Tt, int Ts, int T_da
   return ctx ? ctx->eng->reserve_workspace(B, S, Tt, Ts, T_dac) : ECHO_ERR;
 }
 
+int echo_fp8_calibrate(echo_ctx* ctx, int on) { return ctx ? ctx->eng->fp8_calibrate(on) : ECHO_ERR; }
+int echo_fp8_calibration(echo_ctx* ctx, float* out, int n) { return ctx ? ctx->eng->fp8_calibration(out, n) : ECHO_ERR; }
+int echo_fp8_set_static_scales(echo_ctx* ctx, const float* scales, int n) { return ctx ? ctx->eng->fp8_set_static(scales, n) : ECHO_ERR; }
+
 int echo_set_profiling(echo_ctx* ctx, int on) { if (!ctx) return ECHO_ERR; ctx->eng->profiling = on != 0; return ECHO_OK; }
 int echo_get_profile(echo_ctx* ctx, echo_profile* out) { if (!ctx || !out) return ECHO_ERR; *out = ctx->eng->prof; return ECHO_OK; }
 
@@ -2030,6 +2087,7 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
   g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3; g.w_presplit = d->split3 ? d->w_presplit : 0;
   g.fp8 = d->fp8; g.a_scale = d->a_scale; g.w_scale = d->w_scale;
+  g.a_scale_const = d->a_scale_const; g.c8 = d->c8; g.c8_ld = d->c8_ld; g.c8_inv = d->c8_inv;
   g.qkv_mode = d->qkv_mode; g.qkv_D = d->qkv_D; g.qkv_S = d->qkv_S; g.rope_heads = d->rope_heads; g.pos0 = d->pos0; g.qk_eps = d->qk_eps;
   g.qk_w = d->qk_w; g.rope = d->rope; g.vt = d->vt; g.vt_ld = d->vt_ld; g.vt_row_stride = d->vt_row_stride;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
@@ -2048,6 +2106,7 @@ int echo_op_attention_bf16(const echo_attn_desc* d, void* stream) {
   a.O = (bf16_t*)d->O; a.o_ld = d->o_ld; a.o_row_stride = d->o_row_stride;
   a.G = (const bf16_t*)d->G; a.g_ld = d->g_ld; a.g_row_stride = d->g_row_stride;
   a.S = d->S; a.H = d->H; a.rows = d->rows; a.nseg = d->nseg; a.causal = d->causal; a.scale = d->scale; a.prof = d->prof;
+  a.O8 = (uint8_t*)d->O8; a.o8_ld = d->o8_ld; a.o8_row_stride = d->o8_row_stride; a.o8_inv = d->o8_inv;
   for (int s = 0; s < d->nseg && s < 4; ++s) {
     a.seg[s].K = (const bf16_t*)d->seg[s].K; a.seg[s].k_ld = d->seg[s].k_ld; a.seg[s].k_row_stride = d->seg[s].k_row_stride;
     a.seg[s].k_head_stride = d->seg[s].k_head_stride;

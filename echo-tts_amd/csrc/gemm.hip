@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
       // dequantise in the accumulator layout: lane holds C[m_base + 16 i + fr][n_base + 16 jn + 4 fg + r]
       float sa[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr; sa[i] = p.a_scale[m < p.M ? m : p.M - 1]; }
+      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr; sa[i] = p.a_scale ? p.a_scale[m < p.M ? m : p.M - 1] : p.a_scale_const; }
 #pragma unroll
       for (int jn = 0; jn < 8; ++jn) {
         const int n0 = n_base + 16 * jn + 4 * fg;
@@ -980,7 +980,22 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           }
         rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
           const int m = m_base + 16 * i + row, j0 = j_base + 8 * c8;
-          if (m < p.M && j0 < (p.N >> 1)) *(uint4*)(C + (long)m * p.ldc + j0) = pack8_bf16(y);
+          if (m < p.M && j0 < (p.N >> 1)) {
+            if constexpr (FP8) {
+              if (p.c8) {      // static activation scale: e4m3 bytes for the w2 GEMM (the values are bf16-rounded already)
+                float z[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = __builtin_amdgcn_fmed3f(y[e] * p.c8_inv, -448.0f, 448.0f);
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(z[2], z[3], lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(z[4], z[5], 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(z[6], z[7], hi, true);
+                *(int2*)((uint8_t*)p.c8 + (long)m * p.c8_ld + j0) = int2{lo, hi};
+                return;
+              }
+            }
+            *(uint4*)(C + (long)m * p.ldc + j0) = pack8_bf16(y);
+          }
         });
       }
     } else if (p.qkv_mode) {
@@ -1321,10 +1336,11 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
     if ((long)(g.M - 1) * g.lda * es + 128 >= (1L << 32) || (long)(g.Npad - 1) * g.ldw * es + 128 >= (1L << 32)) return hipErrorInvalidValue;
   }
   if (g.fp8 && g.cfg != 5) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel only
+  if (g.c8 && !(g.fp8 && SW && g.ksplit <= 1 && (g.c8_ld & 7) == 0 && g.c8_inv > 0.0f)) return hipErrorInvalidValue;   // e4m3 output: SwiGLU tail of the fp8 kernel only
   if (g.cfg == 5) {
     if constexpr (Num<T>::is_bf16) {
       if (g.fp8) {
-        if (!g.a_scale || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
+        if ((!g.a_scale && !(g.a_scale_const > 0.0f)) || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
         return launch_pp<SW, 0, PP_LEAD, true>(g, st);
       }
       return launch_pp<SW>(g, st);

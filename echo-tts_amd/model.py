@@ -190,6 +190,37 @@ class EchoDiT:
                                                shape, int(t.is_cuda)), self._ctx)
         L.check(self._lib.echo_finalize_dit(self._ctx, self._stream()), self._ctx)
 
+    # ------------------------------------------------------------------ fp8 activation-scale calibration (BASELINE C5)
+    def fp8_calibration_start(self) -> None:
+        """Clears the per-block maxima and records, during every forward / sampler call until `fp8_calibration_finish`, the largest
+        dynamic row scale (amax / 448) of the attention output and of the SwiGLU output of every block (static scales are ignored
+        meanwhile).  Run representative requests in between."""
+        L.check(self._lib.echo_fp8_calibrate(self._ctx, 1), self._ctx)
+
+    def fp8_calibration_finish(self, margin: float = 1.25) -> torch.Tensor:
+        """Stops recording and returns the (num_layers, 2) fp32 tensor of static scales = recorded maximum x `margin` ([:, 0] attention
+        output -> wo, [:, 1] SwiGLU output -> w2).  Blocks that saw no data get the scale 1 / 448 (amax 1).  Install them with
+        `set_fp8_static_scales`; `weights.save_fp8_scales` / `load_fp8_scales` keep them next to a checkpoint."""
+        n = 2 * self.config.num_layers
+        buf = (C.c_float * n)()
+        L.check(self._lib.echo_fp8_calibration(self._ctx, buf, n), self._ctx)
+        L.check(self._lib.echo_fp8_calibrate(self._ctx, 0), self._ctx)
+        t = torch.tensor(list(buf), dtype=torch.float32).reshape(self.config.num_layers, 2)
+        return torch.where(t > 0, t * float(margin), torch.full_like(t, 1.0 / 448.0))
+
+    def set_fp8_static_scales(self, scales: Optional[torch.Tensor]) -> None:
+        """`scales` (num_layers, 2) as returned by `fp8_calibration_finish`: the attention epilogue and the SwiGLU tail then write the
+        e4m3 operands of wo / w2 themselves (values beyond 448 x scale saturate) and the two quantisation passes of a block disappear.
+        None: back to dynamic per-token-row scales."""
+        if scales is None:
+            L.check(self._lib.echo_fp8_set_static_scales(self._ctx, None, 0), self._ctx)
+            return
+        flat = [float(v) for v in scales.detach().float().cpu().reshape(-1)]
+        if len(flat) != 2 * self.config.num_layers:
+            raise L.EchoHipError(f"fp8 static scales: expected {self.config.num_layers} x 2 values, got {len(flat)}")
+        buf = (C.c_float * len(flat))(*flat)
+        L.check(self._lib.echo_fp8_set_static_scales(self._ctx, buf, len(flat)), self._ctx)
+
     def set_profiling(self, on: bool) -> None:
         L.check(self._lib.echo_set_profiling(self._ctx, int(on)), self._ctx)
 

@@ -186,3 +186,22 @@ def fp8_weight_state(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         lin = v.dim() == 2 and k.startswith("blocks.") and (".attention.w" in k or ".attention.gate" in k or ".mlp.w" in k)
         out[k] = fake_quant_fp8_e4m3(v) if lin else v
     return out
+
+
+def save_fp8_scales(path: str, scales: torch.Tensor, meta: Dict[str, object] | None = None) -> None:
+    """Static fp8 activation scales of `EchoDiT.fp8_calibration_finish` as a small JSON file next to a checkpoint
+    ({"scales": [[attention_out, swiglu_out] per block], "meta": {...}})."""
+    import json
+    with open(path, "w") as f:
+        json.dump({"format": "echo-hip fp8 activation scales v1", "scales": [[float(a), float(b)] for a, b in scales.float().cpu().tolist()],
+                   "meta": dict(meta or {})}, f, indent=1)
+
+
+def load_fp8_scales(path: str) -> torch.Tensor:
+    import json
+    with open(path) as f:
+        d = json.load(f)
+    t = torch.tensor(d["scales"], dtype=torch.float32)
+    if t.dim() != 2 or t.shape[1] != 2 or not bool((t > 0).all()) or not bool(torch.isfinite(t).all()):
+        raise ValueError(f"{path}: not a (num_layers, 2) table of positive scales")
+    return t

@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 5
+#define ECHO_ABI_VERSION 6
 
 typedef struct echo_ctx echo_ctx;
 
@@ -107,6 +107,17 @@ void echo_voice_destroy(echo_voice* voice);
  * grows them for a request geometry up front (B utterances per sampler call, S latents, Tt text tokens, Ts speaker latents,
  * T_dac frames per decode) so that the first request allocates nothing. */
 int64_t echo_workspace_bytes(echo_ctx* ctx);
+/* fp8 engine (echo_config.dit_fp8, BASELINE config C5): calibration of static activation scales for the two block operands no producer
+ * can quantise per row (attention output -> wo, SwiGLU output -> w2); SURVEY.md 8f-4 "fp8 calibration".  echo_fp8_calibrate(ctx, 1)
+ * clears the per-block maxima and records, during every forward until echo_fp8_calibrate(ctx, 0), the largest dynamic row scale
+ * (amax / 448) each block sees; echo_fp8_calibration copies the 2 * num_layers values out ([2 l] attention output, [2 l + 1] SwiGLU
+ * output); echo_fp8_set_static_scales installs 2 * num_layers scales (the caller applies its margin; n = 0: back to dynamic row scales):
+ * the attention epilogue and the SwiGLU tail then write the e4m3 operands themselves and both quantisation passes of a block go away.
+ * Values beyond 448 * scale saturate.  The reference has no fp8 path: this is this engine's own stated arithmetic (oracle:
+ * set_fp8_block_linears(True, act_static=...)). */
+int echo_fp8_calibrate(echo_ctx* ctx, int on);
+int echo_fp8_calibration(echo_ctx* ctx, float* out, int n);
+int echo_fp8_set_static_scales(echo_ctx* ctx, const float* scales, int n);
 int echo_reserve_workspace(echo_ctx* ctx, int B, int S, int Tt, int Ts, int T_dac);
 
 /* model.py:563-604 EchoDiT.forward for `rows` = R*B rows that share one timestep.
@@ -187,6 +198,10 @@ typedef struct {
   int qkv_mode, qkv_D, qkv_S, rope_heads, pos0; float qk_eps;
   const void* qk_w; const void* rope; void* vt; int64_t vt_ld, vt_row_stride;
   int w_presplit;                /* split3 only: W was reformatted in place by echo_op_presplit_weights (static weights) */
+  /* ABI 6, fp8 with a static (calibrated) activation scale: a_scale == NULL -> every A row has the scale a_scale_const (> 0);
+   * c8 != NULL (fp8 + swiglu only): the SwiGLU output leaves as e4m3(bf16(out) * c8_inv) bytes at c8 (row pitch c8_ld bytes, % 8 == 0,
+   * saturating at +-448) instead of bf16 at C - the A operand of the next fp8 GEMM without a quantisation pass */
+  float a_scale_const; void* c8; int64_t c8_ld; float c8_inv;
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 /* In-place reformat of an fp32 weight matrix (rows x ld, ld % 32 == 0) for w_presplit: every aligned block of 32 floats becomes
@@ -211,6 +226,9 @@ typedef struct {
   void* prof;                    /* diagnostic build only: (workgroups*4, 4) uint64 cycle sums; NULL normally */
   void* redo;                    /* optional device scratch of rows * H * ceil(S / 256) int32 for the fast kernel's range report (DESIGN.md
                                     3.2); NULL: the library uses a buffer of its own per host thread and device */
+  /* ABI 6: O8 != NULL -> the (gated) output is written as e4m3(bf16(out) * o8_inv) bytes to O8 (same indexing as O, pitches in bytes,
+   * o8_ld % 4 == 0, saturating) INSTEAD of bf16 to O: wo's fp8 operand under a static activation scale (echo_fp8_set_static_scales) */
+  void* O8; int64_t o8_ld, o8_row_stride; float o8_inv;
 } echo_attn_desc;
 int echo_op_attention_bf16(const echo_attn_desc* d, void* stream);
 

@@ -163,11 +163,15 @@ def lowrank_adaln(w: Weights, p: str, x: Tensor, cond: Tensor, eps: float) -> Tu
 # weights scaled per output row and activations per token row by amax / 448, products accumulated in fp32, result rounded to the
 # model dtype.  Off by default; tests switch it on to pin the engine's fp8 path to something other than itself.
 _FP8_BLOCK_LINEARS = False
+_FP8_ACT_STATIC: Optional[Dict[str, float]] = None
 
 
-def set_fp8_block_linears(on: bool) -> None:
-    global _FP8_BLOCK_LINEARS
+def set_fp8_block_linears(on: bool, act_static: Optional[Dict[str, float]] = None) -> None:
+    """C5 restatement switch.  `act_static` (engine option `EchoDiT.set_fp8_static_scales`): {"<block prefix>.wo": s, "<block prefix>.w2": s}
+    - the activation operand of that linear is quantised with the one calibrated scale s (saturating at 448 s) instead of per token row."""
+    global _FP8_BLOCK_LINEARS, _FP8_ACT_STATIC
     _FP8_BLOCK_LINEARS = bool(on)
+    _FP8_ACT_STATIC = dict(act_static) if (on and act_static) else None
 
 
 def fake_quant_rows_e4m3(x: Tensor) -> Tensor:
@@ -176,16 +180,22 @@ def fake_quant_rows_e4m3(x: Tensor) -> Tensor:
     return (xf / s).to(torch.float8_e4m3fn).float() * s
 
 
-def block_linear(x: Tensor, wt: Tensor, p: str) -> Tensor:
+def fake_quant_static_e4m3(x: Tensor, s: float) -> Tensor:
+    return (x.float() / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * s
+
+
+def block_linear(x: Tensor, wt: Tensor, p: str, name: str = "") -> Tensor:
     """nn.Linear of an EchoDiT block (attention wq / wk / wv / gate / wo, mlp w1 / w3 / w2); fp8 operands when C5 mode is on."""
     if _FP8_BLOCK_LINEARS and p.startswith("blocks."):
-        return (fake_quant_rows_e4m3(x) @ fake_quant_rows_e4m3(wt).t()).to(x.dtype)
+        st = _FP8_ACT_STATIC.get(f"{p}.{name}") if (_FP8_ACT_STATIC and name) else None
+        xq = fake_quant_static_e4m3(x, st) if st is not None else fake_quant_rows_e4m3(x)
+        return (xq @ fake_quant_rows_e4m3(wt).t()).to(x.dtype)
     return F.linear(x, wt)
 
 
 def swiglu(w: Weights, p: str, x: Tensor) -> Tensor:
     """w2(silu(w1 x) * w3 x).  model.py:307-308."""
-    return block_linear(F.silu(block_linear(x, w[f"{p}.w1.weight"], p)) * block_linear(x, w[f"{p}.w3.weight"], p), w[f"{p}.w2.weight"], p)
+    return block_linear(F.silu(block_linear(x, w[f"{p}.w1.weight"], p)) * block_linear(x, w[f"{p}.w3.weight"], p), w[f"{p}.w2.weight"], p, "w2")
 
 
 def encoder_self_attention(w: Weights, p: str, x: Tensor, mask: Optional[Tensor], fc: Tensor,
@@ -205,7 +215,7 @@ def encoder_self_attention(w: Weights, p: str, x: Tensor, mask: Optional[Tensor]
         query=q.transpose(1, 2), key=k.transpose(1, 2), value=v.transpose(1, 2), attn_mask=am, is_causal=causal
     ).transpose(1, 2)
     o = o.reshape(b, s, -1) * torch.sigmoid(g)
-    return block_linear(o, w[f"{p}.wo.weight"], p)
+    return block_linear(o, w[f"{p}.wo.weight"], p, "wo")
 
 
 def encoder_block(w: Weights, p: str, x: Tensor, mask: Optional[Tensor], fc: Tensor,
@@ -311,7 +321,7 @@ def joint_attention(w: Weights, cfg: DiTConfig, p: str, x: Tensor, text_mask: Te
         query=q.transpose(1, 2), key=kk.transpose(1, 2), value=vv.transpose(1, 2), attn_mask=m, is_causal=False
     ).transpose(1, 2)
     o = o.reshape(b, s, -1) * torch.sigmoid(g)
-    return block_linear(o, w[f"{p}.wo.weight"], p)
+    return block_linear(o, w[f"{p}.wo.weight"], p, "wo")
 
 
 def dit_forward(w: Weights, cfg: DiTConfig, x: Tensor, t: Tensor, text_mask: Tensor, speaker_mask: Tensor,

@@ -38,7 +38,7 @@ def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
 def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C2=None, taps=1, tap_base=0, tap_shift=0,
          nbatch=1, nbi=1, a_bo=0, a_bi=0, w_bo=0, w_bi=0, c_bo=0, c_bi=0, acc_scale=1.0, bias=None, bias_bo=0, bias_bi=0,
          vec_mod=0, div=0.0, act=0, colscale=None, res=None, ldres=0, res_bo=0, res_bi=0, snake_alpha=None, store_main=1,
-         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None, qkv=None, w_presplit=0):
+         swiglu=0, Npad=None, a_offset_elems=0, cfg=0, ksplit=1, split3=0, ws=None, a_scale=None, w_scale=None, qkv=None, w_presplit=0, a_scale_const=0.0, c8=None, c8_inv=0.0):
     d = L.EchoGemmDesc()
     es = A.element_size()
     d.A = A.data_ptr() + a_offset_elems * es
@@ -57,8 +57,10 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     d.snake_alpha = ptr(snake_alpha)
     d.store_main, d.swiglu = store_main, swiglu
     d.cfg, d.ksplit, d.split3, d.w_presplit = cfg, ksplit, split3, w_presplit
-    if a_scale is not None:   # e4m3 operands: A / W are uint8 tensors, the output C decides the dtype code
-        d.fp8, d.a_scale, d.w_scale = 1, a_scale.data_ptr(), w_scale.data_ptr()
+    if a_scale is not None or a_scale_const:   # e4m3 operands: A / W are uint8 tensors, the output C decides the dtype code
+        d.fp8, d.a_scale, d.w_scale, d.a_scale_const = 1, ptr(a_scale), w_scale.data_ptr(), a_scale_const
+    if c8 is not None:        # SwiGLU tail of the fp8 kernel writing e4m3 bytes (static activation scale)
+        d.c8, d.c8_ld, d.c8_inv = c8.data_ptr(), c8.stride(0), c8_inv
     if qkv is not None:       # fused QKV(G) tail: dict(D, S, rope_heads, pos0, eps, qk_w, rope, vt, vt_ld, vt_row_stride)
         d.qkv_mode, d.qkv_D, d.qkv_S, d.rope_heads, d.pos0, d.qk_eps = 1, qkv["D"], qkv["S"], qkv["rope_heads"], qkv.get("pos0", 0), qkv["eps"]
         d.qk_w, d.rope, d.vt, d.vt_ld, d.vt_row_stride = qkv["qk_w"].data_ptr(), qkv["rope"].data_ptr(), qkv["vt"].data_ptr(), qkv["vt_ld"], qkv["vt_row_stride"]
@@ -68,7 +70,7 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
         need = ksplit * ((M + 767) // 768 * 768) * d.Npad * 4   # rows padded for every tile height (128 / 256 / 384)
         ws = torch.empty((need,), dtype=torch.uint8, device=A.device)
         d.ws, d.ws_bytes = ws.data_ptr(), need
-    L.check(lib().echo_op_gemm(code(C_out if a_scale is not None else A), C.byref(d), stream()))
+    L.check(lib().echo_op_gemm(code(C_out if (a_scale is not None or a_scale_const) else A), C.byref(d), stream()))
 
 
 def pack_swiglu(w1: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:

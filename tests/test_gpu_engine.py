@@ -5,6 +5,8 @@ Tolerances (BASELINE.json north_star): latents <= 1e-3 RMS, waveform <= 1e-4 RMS
 fp32 engine against the fp32 reference.  The bf16 engine cannot meet 1e-3 against a bf16 PyTorch
 run any more than PyTorch meets it against itself, so it is held to: no farther
 from the fp32 reference than 1.5x the reference's own bf16 run (+1e-3)."""
+import os
+
 import pytest
 import torch
 
@@ -16,6 +18,7 @@ from tests.golden_defs import SAMPLER_CASES, TINY, TINY_DAC, WIDE1  # noqa: E402
 
 import echo_tts_amd as E  # noqa: E402
 from echo_tts_amd.inference import _concat_kv_caches  # noqa: E402
+from echo_tts_amd import _lib as L  # noqa: E402
 
 DEV = U.DEV
 LAT_TOL = 1e-3
@@ -669,6 +672,64 @@ def test_fp8_engine_against_fake_quant_restatement(golden):
         print(f"C5 fp8 engine vs fake-quant restatement (d = {cfg.model_size}): rms {e:.3e}; fp8's own effect (restatement vs bf16) {effect:.3e}; "
               f"output rms {U.rms(want):.3f}")
         assert effect > 0 and e < 0.5 * effect + 2e-3 * U.rms(want), (e, effect)
+
+
+def test_fp8_static_activation_scales_calibration_and_restatement(golden):
+    """SURVEY 8f-4 "fp8 calibration" (C5): `fp8_calibration_start` / `_finish` record the largest dynamic row scale of the attention output
+    and of the SwiGLU output per block; with those installed (`set_fp8_static_scales`) the attention epilogue and the SwiGLU tail write
+    the e4m3 operands of wo / w2 themselves.  Pinned like the dynamic engine: at full width and on the tiny model one velocity prediction
+    must be much closer to the oracle's restatement of THAT arithmetic (`set_fp8_block_linears(True, act_static=...)`: one calibrated
+    scale for those two operands, saturating) than the restatement is to plain bf16; it stays close to the dynamic engine; clearing the
+    scales gives the dynamic engine's bits back; a scale table of the wrong size fails loudly."""
+    for cfg, S, T in ((WIDE1, 200, 40), (TINY, 32, 24)):
+        wb = {k: v.bfloat16() for k, v in R.make_dit_weights(cfg, seed=0).items()}
+        gen = torch.Generator().manual_seed(3)
+        ids = torch.randint(1, 256, (1, T), generator=gen, dtype=torch.int32)
+        tmask = torch.ones((1, T), dtype=torch.bool)
+        spk, smask = torch.randn((1, 64, 80), generator=gen).bfloat16(), torch.ones((1, 64), dtype=torch.bool)
+        x = torch.randn((1, S, 80), generator=gen).bfloat16()
+        t = torch.full((1,), 0.75).bfloat16()
+        m8 = E.EchoDiT(cfg, wb, dtype=torch.bfloat16, device=DEV, fp8=True)
+        fwd = lambda: m8(x, t, tmask, smask, m8.get_kv_cache_text(ids, tmask), m8.get_kv_cache_speaker(spk, smask)).float().cpu()
+        dyn = fwd()
+        m8.fp8_calibration_start()
+        during = fwd()
+        scales = m8.fp8_calibration_finish(margin=1.0)
+        assert torch.equal(during, dyn), "recording the maxima changed the forward"
+        assert scales.shape == (cfg.num_layers, 2) and bool((scales > 0).all()) and bool(torch.isfinite(scales).all())
+        m8.set_fp8_static_scales(scales)
+        got = fwd()
+        assert torch.equal(got, fwd()), "the static-scale forward is not reproducible"
+        kvt, kvs = R.kv_cache_text(wb, cfg, ids, tmask), R.kv_cache_speaker(wb, cfg, spk)
+        plain = R.dit_forward(wb, cfg, x, t, tmask, smask, kvt, kvs)
+        act = {}
+        for i in range(cfg.num_layers):
+            act[f"blocks.{i}.attention.wo"] = float(scales[i, 0])
+            act[f"blocks.{i}.mlp.w2"] = float(scales[i, 1])
+        R.set_fp8_block_linears(True, act_static=act)
+        try:
+            want = R.dit_forward(wb, cfg, x, t, tmask, smask, kvt, kvs)
+        finally:
+            R.set_fp8_block_linears(False)
+        e, effect, vs_dyn = rms(got, want), rms(want, plain), rms(got, dyn)
+        print(f"C5 static activation scales (d = {cfg.model_size}): rms {e:.3e} vs the static restatement; fp8's own effect {effect:.3e}; "
+              f"static vs dynamic engine {vs_dyn:.3e}; output rms {U.rms(want):.3f}; scales {scales.min():.3e} .. {scales.max():.3e}")
+        assert effect > 0 and e < 0.6 * effect + 2e-3 * U.rms(want), (e, effect)      # measured 0.47 / 0.50 of the effect (d = 2048 / 256)
+        assert vs_dyn < 1.0 * effect + 2e-3 * U.rms(want), (vs_dyn, effect)            # measured 0.76 / 0.83
+        # half the calibrated range: the operands saturate, the forward stays finite and moves away
+        m8.set_fp8_static_scales(scales * 0.25)
+        sat = fwd()
+        assert bool(torch.isfinite(sat).all()) and rms(sat, got) > 0
+        m8.set_fp8_static_scales(None)
+        assert torch.equal(fwd(), dyn), "clearing the static scales did not restore the dynamic path"
+        with pytest.raises(L.EchoHipError):
+            m8.set_fp8_static_scales(torch.ones((cfg.num_layers + 1, 2)))
+    # the scales travel as a small JSON file next to a checkpoint
+    import tempfile
+    from echo_tts_amd import weights as Wt
+    with tempfile.TemporaryDirectory() as td:
+        Wt.save_fp8_scales(os.path.join(td, "s.json"), scales, {"note": "test"})
+        assert torch.equal(Wt.load_fp8_scales(os.path.join(td, "s.json")), scales)
 
 
 def test_voice_cloning_pipeline_from_audio(golden, tiny_models):

@@ -214,6 +214,63 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
     # bf16 outputs: one ulp of a value in [4, 8) is 2^-5 - the bound is 3e-2 plus one bf16 ulp of the reference's magnitude
     assert float((err - refr.abs() * 2.0 ** -7).max()) < 3e-2, float(err.max())
     assert float(err.mean()) < 2e-3, float(err.mean())
+    # e4m3 output (ABI 6, fp8 engine with a static activation scale): the same launch with O8 writes e4m3(bf16(out) * inv), saturating
+    _check_attention_fp8_output(d, out, R * S, H * 128, inv=448.0 / float(out.float().abs().max()) * 1.5)      # the largest values saturate at 448
+
+
+def _check_attention_fp8_output(d, out_bf16, rows, width, inv):
+    """Re-launches the attention described by `d` with an e4m3 destination and compares the bytes with a torch quantisation of the
+    bf16 output the first launch produced (v_cvt_pk_fp8_f32 vs torch: near-ties may land on the neighbouring code, see
+    test_quant_rows_fp8_matches_torch_e4m3); the bf16 destination must stay untouched."""
+    import os
+    if os.environ.get("ECHO_ATTN") == "4":
+        return      # attn4_kernel has no e4m3 output: the launcher takes attn5_kernel for it, whose bf16 roundings differ from attn4's in places
+    o8 = torch.full((rows, width + 4), 0x55, dtype=torch.uint8, device=DEV)
+    keep = out_bf16.clone()
+    d.O8, d.o8_ld, d.o8_row_stride, d.o8_inv = o8.data_ptr(), width + 4, (rows // d.rows) * (width + 4), inv
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    d.O8 = None
+    assert torch.equal(out_bf16, keep), "the bf16 output was written although an e4m3 destination was given"
+    assert bool((o8[:, width:] == 0x55).all()), "bytes beyond the row were written"
+    want = (keep.float().reshape(rows, width) * inv).clamp(-448.0, 448.0)
+    got, ref = _deq(o8[:, :width].contiguous()), _deq(_to_e4m3_bytes(want))
+    assert bool(torch.isfinite(got).all())
+    bad = got != ref
+    assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
+    step = ref.abs().clamp_min(2.0 ** -6) * 0.126
+    assert bool(((got - ref).abs()[bad] <= step[bad] * 1.0001).all())
+    assert float((got.abs() == 448.0).float().mean()) > 0, "the saturation branch was not exercised"
+
+
+def test_attention_fp8_output_two_stream_blocks():
+    """The 256-query workgroups of attn5_kernel (two query streams per wave) + its short last block with the e4m3 output: a grid of more
+    than one round (6 rows x 16 heads x 3 blocks of 128 > 256 workgroups), S = 320 = one 256-query block + one of 64."""
+    R, S, H, Lt = 6, 320, 16, 70
+    D = H * 128
+    qkvg = rnd(R * S + 256, 4 * D, dtype=torch.bfloat16, scale=0.5)
+    pS, pT = (S + 63) // 64 * 64, (Lt + 63) // 64 * 64
+    vt_self = rnd(R, H, 128, pS, dtype=torch.bfloat16, seed=1)
+    kt, vt_t = rnd(Lt + 128, 4 * D, dtype=torch.bfloat16, seed=2), rnd(1, H, 128, pT, dtype=torch.bfloat16, seed=3)
+    nk = torch.tensor([[S] * R, [Lt, 0, Lt, Lt, 0, Lt]], dtype=torch.int32, device=DEV)
+    out = torch.zeros((R * S, D), dtype=torch.bfloat16, device=DEV)
+    d = L.EchoAttnDesc()
+    d.Q, d.q_ld, d.q_row_stride = qkvg.data_ptr(), 4 * D, S * 4 * D
+    d.O, d.o_ld, d.o_row_stride = out.data_ptr(), D, S * D
+    d.G, d.g_ld, d.g_row_stride = qkvg.data_ptr() + 3 * D * 2, 4 * D, S * 4 * D
+    d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 2, 0, 1 / math.sqrt(128)
+    for i, (kp, kld, krs, vt, pitch, shared) in enumerate(((qkvg.data_ptr() + D * 2, 4 * D, S * 4 * D, vt_self, pS, False),
+                                                           (kt.data_ptr(), 4 * D, 0, vt_t, pT, True))):
+        sg = d.seg[i]
+        sg.K, sg.k_ld, sg.k_head_stride, sg.k_row_stride = kp, kld, 128, krs
+        sg.Vt, sg.vt_ld, sg.vt_head_stride = vt.data_ptr(), pitch, 128 * pitch
+        sg.vt_row_stride = 0 if shared else H * 128 * pitch
+        sg.nkeys = nk[i].data_ptr()
+        sg.kv_mod = 1 if shared else 0
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    assert bool(out.any())
+    _check_attention_fp8_output(d, out, R * S, D, inv=448.0 / float(out.float().abs().max()) * 1.5)
 
 
 @pytest.mark.parametrize("variant", ["1", "4", "5"])
@@ -779,3 +836,19 @@ def test_gemm_pingpong_fp8_exact_on_integers_and_swiglu():
     blk = full[:, :2 * F].reshape(M2, F // 16, 2, 16)
     ya, yb = blk[:, :, 0].reshape(M2, F).bfloat16(), blk[:, :, 1].reshape(M2, F).bfloat16()
     U.bf16_close(o2, (torch.nn.functional.silu(ya.float()).bfloat16().float() * yb.float()).bfloat16(), ulps=2.0, atol=2e-3)
+    # ABI 6, static activation scales: a_scale == NULL + a_scale_const equals a constant scale vector bit for bit, and the SwiGLU
+    # tail's e4m3 output (c8) is the quantisation of the bf16 output of the same launch (saturating)
+    cs = float(sa.mean())
+    o3, o4 = torch.zeros_like(o2), torch.zeros_like(o2)
+    U.gemm(a8, w8, o3, M=M2, N=2 * F, K=K2, lda=K2, ldw=K2, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=5, a_scale=torch.full_like(sa, cs), w_scale=sw)
+    U.gemm(a8, w8, o4, M=M2, N=2 * F, K=K2, lda=K2, ldw=K2, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=5, a_scale_const=cs, w_scale=sw)
+    assert torch.equal(o3, o4) and bool(o3.any())
+    inv = 448.0 / float(o3.float().abs().max()) * 1.5
+    c8 = torch.full((M2, F + 8), 0x55, dtype=torch.uint8, device=DEV)
+    o5 = torch.zeros_like(o2)
+    U.gemm(a8, w8, o5, M=M2, N=2 * F, K=K2, lda=K2, ldw=K2, ldc=F, swiglu=1, Npad=Wp.shape[0], cfg=5, a_scale_const=cs, w_scale=sw, c8=c8, c8_inv=inv)
+    assert not bool(o5.any()) and bool((c8[:, F:] == 0x55).all())
+    got, ref = _deq(c8[:, :F].contiguous()), _deq(_to_e4m3_bytes((o3.float() * inv).clamp(-448.0, 448.0)))
+    bad = got != ref
+    assert float(bad.float().mean()) < 2e-3 and bool(((got - ref).abs()[bad] <= ref.abs().clamp_min(2.0 ** -6)[bad] * 0.1261).all())
+    assert float((got.abs() == 448.0).float().mean()) > 0

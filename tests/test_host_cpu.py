@@ -160,3 +160,31 @@ def _build_c_caller(tmp_path):
 
 def test_header_is_plain_c_and_links(tmp_path):
     _build_c_caller(tmp_path)
+
+
+def test_fp8_static_scale_helpers(tmp_path):
+    """the calibrated fp8 activation scales travel as JSON; the oracle's restatement of the static mode quantises the named
+    operand with the one scale (saturating at 448 s) and leaves every other block linear on per-row scales."""
+    import torch
+    from echo_tts_amd import weights as W
+    from oracle import echo_ref as R
+    t = torch.tensor([[0.01, 0.5], [0.02, 0.25], [3.0, 1e-3]])
+    W.save_fp8_scales(str(tmp_path / "s.json"), t, {"model": "unit"})
+    assert torch.equal(W.load_fp8_scales(str(tmp_path / "s.json")), t)
+    (tmp_path / "bad.json").write_text('{"scales": [[1.0, -2.0]]}')
+    import pytest
+    with pytest.raises(ValueError):
+        W.load_fp8_scales(str(tmp_path / "bad.json"))
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn((5, 64), generator=g) * 3, torch.randn((8, 64), generator=g)
+    q = R.fake_quant_static_e4m3(x, 0.01)
+    assert abs(float(q.abs().max()) - 4.48) < 1e-6                  # saturates at 448 s
+    assert torch.equal(R.fake_quant_static_e4m3(x, 1.0), x.to(torch.float8_e4m3fn).float())
+    R.set_fp8_block_linears(True, act_static={"blocks.0.mlp.w2": 0.01})
+    try:
+        a, b = R.block_linear(x, w, "blocks.0.mlp", "w2"), R.block_linear(x, w, "blocks.0.mlp", "w1")
+        c = R.block_linear(x, w, "blocks.1.mlp", "w2")
+    finally:
+        R.set_fp8_block_linears(False)
+    assert not torch.equal(a, b) and torch.equal(b, c)
+    assert torch.equal(R.block_linear(x, w, "blocks.0.mlp", "w2"), torch.nn.functional.linear(x, w))   # switched off again
