@@ -72,7 +72,7 @@ class EchoGemmDesc(C.Structure):
                 ("fp8", C.c_int), ("a_scale", vp), ("w_scale", vp),
                 ("qkv_mode", C.c_int), ("qkv_D", C.c_int), ("qkv_S", C.c_int), ("rope_heads", C.c_int), ("pos0", C.c_int), ("qk_eps", C.c_float),
                 ("qk_w", vp), ("rope", vp), ("vt", vp), ("vt_ld", c_i64), ("vt_row_stride", c_i64), ("w_presplit", C.c_int),
-                ("a_scale_const", C.c_float), ("c8", vp), ("c8_ld", c_i64), ("c8_inv", C.c_float)]
+                ("a_scale_const", C.c_float), ("c8", vp), ("c8_ld", c_i64), ("c8_inv", C.c_float), ("qkv_gate_act", C.c_int)]
 
 
 class EchoAttnSeg(C.Structure):
@@ -87,7 +87,7 @@ class EchoAttnDesc(C.Structure):
                 ("G", vp), ("g_ld", c_i64), ("g_row_stride", c_i64),
                 ("S", C.c_int), ("H", C.c_int), ("rows", C.c_int), ("nseg", C.c_int),
                 ("seg", EchoAttnSeg * 4), ("causal", C.c_int), ("scale", C.c_float), ("prof", vp), ("redo", vp),
-                ("O8", vp), ("o8_ld", c_i64), ("o8_row_stride", c_i64), ("o8_inv", C.c_float)]
+                ("O8", vp), ("o8_ld", c_i64), ("o8_row_stride", c_i64), ("o8_inv", C.c_float), ("g_activated", C.c_int)]
 
 
 class EchoProfile(C.Structure):

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
         float gv[4];
         Vec4<bf16_t>::unpack(gq[d][g], gv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
+        for (int i = 0; i < 4; ++i) y[i] = y[i] * (p.g_act ? gv[i] : bf2f(f2bf(sigmoid_fast(gv[i]))));
       }
       if (p.O8) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + col, y, p.o8_inv);
       else *(uint2*)(op + col) = Vec4<bf16_t>::pack(y);
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(256, 1) attn4_kernel(const AttnArgs p) {
           float gv[4];
           Vec4<bf16_t>::unpack(gq[d][g], gv);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
+          for (int i = 0; i < 4; ++i) y[i] = y[i] * (p.g_act ? gv[i] : bf2f(f2bf(sigmoid_fast(gv[i]))));      // wave-uniform
         }
         *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
       }
@@ -1348,22 +1348,30 @@ __device__ __forceinline__ void attn5_body(const AttnArgs& p) {
     if (qb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float inv_l = 1.0f / st[qb].l;
     bf16_t* op = p.O + (long)row * p.o_row_stride + (long)q * p.o_ld + head * HD + 4 * fh;
+    // GM: 0 = no gate, 1 = raw gate (sigmoid here), 2 = the QKVG tail stored bf16(sigmoid(gate)) already (AttnArgs.g_act): one
+    // wave-uniform choice per stream instead of a branch per four outputs
+    auto rows_out = [&](auto gmc) __attribute__((always_inline)) {
+      constexpr int GM = decltype(gmc)::value;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float y[4];
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[qb][d][4 * g + i] * inv_l));
-        if (gp) {
-          float gv[4];
-          Vec4<bf16_t>::unpack(gq[qb][d][g], gv);
+          for (int i = 0; i < 4; ++i) y[i] = bf2f(f2bf(o[qb][d][4 * g + i] * inv_l));
+          if constexpr (GM != 0) {
+            float gv[4];
+            Vec4<bf16_t>::unpack(gq[qb][d][g], gv);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = y[i] * bf2f(f2bf(sigmoid_fast(gv[i])));
+            for (int i = 0; i < 4; ++i) y[i] = y[i] * (GM == 2 ? gv[i] : bf2f(f2bf(sigmoid_fast(gv[i]))));
+          }
+          if constexpr (DIAG & 256) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + 4 * fh + 32 * d + 8 * g, y, p.o8_inv);
+          else *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
         }
-        if constexpr (DIAG & 256) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + 4 * fh + 32 * d + 8 * g, y, p.o8_inv);
-        else *(uint2*)(op + 32 * d + 8 * g) = Vec4<bf16_t>::pack(y);
-      }
+    };
+    if (!gp) rows_out(I0{});
+    else if (p.g_act) rows_out(std::integral_constant<int, 2>{});
+    else rows_out(I1{});
   }
   if constexpr (DIAG & 4) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -133,6 +133,8 @@ struct GemmArgs {
   // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
   // position pos0 + (m % qkv_S); the v section is written TRANSPOSED to vt[(m / S)][h][d][m % S]; gate is stored as is.
   int qkv_mode, qkv_D, qkv_S, rope_heads, pos0;
+  int qkv_gate_act;             // bf16 only: the gate section is stored as bf16(sigmoid_fast(bf16(acc))) - what the attention epilogue would
+                                // compute from it (AttnArgs.g_act = 1 then takes it as the multiplier): same bits, the exponentials ride in the GEMM tail
   float qk_eps;
   const void* qk_w; const void* rope;
   void* vt; long vt_ld, vt_row_stride;
@@ -157,6 +159,7 @@ struct AttnArgs {
   const bf16_t* Q; long q_ld, q_row_stride;
   bf16_t* O; long o_ld, o_row_stride;
   const bf16_t* G; long g_ld, g_row_stride;   // optional pre-sigmoid gate, same indexing as O
+  int g_act;                    // 1: G already holds bf16(sigmoid(gate)) (GemmArgs.qkv_gate_act): the epilogue only multiplies
   int S, H, rows;
   int nseg; AttnSeg seg[4];
   int causal;                   // only with nseg == 1 (encoder self-attention)

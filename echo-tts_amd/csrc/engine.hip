@@ -612,7 +612,7 @@ struct Engine : EngineBase {
   };
   // q/gate/out live in [rows*S][..] buffers with per-row stride S*ld
   int attention(const T* q, long q_ld, const T* gate, long g_ld, T* out, long o_ld, int rows, int S, int H, const SegDesc* segs,
-                int nseg, bool causal, hipStream_t st, uint8_t* out8 = nullptr, long o8_ld = 0, float o8_inv = 0.f) {
+                int nseg, bool causal, hipStream_t st, uint8_t* out8 = nullptr, long o8_ld = 0, float o8_inv = 0.f, int g_act = 0) {
     const int* nk = b_nkeys.as<int>();
     if constexpr (Num<T>::is_bf16) {
       AttnArgs a;
@@ -621,6 +621,7 @@ struct Engine : EngineBase {
       a.O = out; a.o_ld = o_ld; a.o_row_stride = (long)S * o_ld;
       a.G = gate; a.g_ld = g_ld; a.g_row_stride = (long)S * g_ld;
       a.O8 = out8; a.o8_ld = o8_ld; a.o8_row_stride = (long)S * o8_ld; a.o8_inv = o8_inv;
+      a.g_act = g_act;
       a.S = S; a.H = H; a.rows = rows; a.causal = causal ? 1 : 0; a.scale = 1.0f / sqrtf(128.0f);
       int n = 0;
       for (int s = 0; s < nseg; ++s) {
@@ -1106,6 +1107,8 @@ struct Engine : EngineBase {
       max_text = std::max(max_text, host_nk[2 * MAXROWS + r]);
       max_spk = std::max(max_spk, host_nk[3 * MAXROWS + r]);
     }
+    static const bool gate_act_on = getenv("ECHO_GATE_ACT") ? atoi(getenv("ECHO_GATE_ACT")) != 0 : true;     // 0: sigmoid in the attention epilogue (A/B aid)
+    const int gate_act = (Num<T>::is_bf16 && D % 256 == 0 && gate_act_on) ? 1 : 0;
     for (int l = 0; l < L; ++l) {
       const T* ma = modrow + (long)(2 * l) * 3 * D;
       const T* mm = modrow + (long)(2 * l + 1) * 3 * D;
@@ -1123,6 +1126,7 @@ struct Engine : EngineBase {
         GemmArgs g = G(xn, D, wqkvg[l], D, qkvg, 4 * D, M, 4 * D, D);
         g.qkv_mode = 1; g.qkv_D = D; g.qkv_S = S; g.rope_heads = H / 2; g.pos0 = start_pos; g.qk_eps = cfg.norm_eps;
         g.qk_w = qkn + (long)l * 2 * D; g.rope = rope; g.vt = vts; g.vt_ld = Sp; g.vt_row_stride = (long)D * Sp;
+        g.qkv_gate_act = gate_act;       // bf16: the gate leaves the GEMM as bf16(sigmoid(gate)), the attention epilogue only multiplies
         if (fp8) CKI(to_fp8(g, q_wqkvg[l], s_wqkvg[l], st, nq1));
         CKI(run(g, st));
       } else {
@@ -1155,13 +1159,13 @@ struct Engine : EngineBase {
       if (st8) {
         CKI(fp8_reserve(M, std::max(D, F)));
         CK(b_h8.reserve((size_t)(M + 256) * F));
-        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, b_q8.as<uint8_t>(), D, 1.0f / fp8_static[2 * l]));
+        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, b_q8.as<uint8_t>(), D, 1.0f / fp8_static[2 * l], gate_act));
         GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
         g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
         g.A = b_q8.p; g.lda = D; g.W = q_wo[l]; g.ldw = D; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l]; g.w_scale = s_wo[l];
         CKI(run(g, st));
       } else {
-        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st));
+        CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, nullptr, 0, 0.f, gate_act));
         GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
         g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
         if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st, false, 2 * l));
@@ -2087,7 +2091,7 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {
   g.snake_alpha = d->snake_alpha; g.store_main = d->store_main; g.swiglu = d->swiglu;
   g.cfg = d->cfg; g.ksplit = d->ksplit; g.ws = d->ws; g.ws_bytes = d->ws_bytes; g.split3 = d->split3; g.w_presplit = d->split3 ? d->w_presplit : 0;
   g.fp8 = d->fp8; g.a_scale = d->a_scale; g.w_scale = d->w_scale;
-  g.a_scale_const = d->a_scale_const; g.c8 = d->c8; g.c8_ld = d->c8_ld; g.c8_inv = d->c8_inv;
+  g.a_scale_const = d->a_scale_const; g.c8 = d->c8; g.c8_ld = d->c8_ld; g.c8_inv = d->c8_inv; g.qkv_gate_act = d->qkv_gate_act;
   g.qkv_mode = d->qkv_mode; g.qkv_D = d->qkv_D; g.qkv_S = d->qkv_S; g.rope_heads = d->rope_heads; g.pos0 = d->pos0; g.qk_eps = d->qk_eps;
   g.qk_w = d->qk_w; g.rope = d->rope; g.vt = d->vt; g.vt_ld = d->vt_ld; g.vt_row_stride = d->vt_row_stride;
   return op_status(dtype == ECHO_BF16 ? launch_gemm_nt<bf16_t>(g, (hipStream_t)stream) : launch_gemm_nt<float>(g, (hipStream_t)stream));
@@ -2106,7 +2110,7 @@ int echo_op_attention_bf16(const echo_attn_desc* d, void* stream) {
   a.O = (bf16_t*)d->O; a.o_ld = d->o_ld; a.o_row_stride = d->o_row_stride;
   a.G = (const bf16_t*)d->G; a.g_ld = d->g_ld; a.g_row_stride = d->g_row_stride;
   a.S = d->S; a.H = d->H; a.rows = d->rows; a.nseg = d->nseg; a.causal = d->causal; a.scale = d->scale; a.prof = d->prof;
-  a.O8 = (uint8_t*)d->O8; a.o8_ld = d->o8_ld; a.o8_row_stride = d->o8_row_stride; a.o8_inv = d->o8_inv;
+  a.O8 = (uint8_t*)d->O8; a.o8_ld = d->o8_ld; a.o8_row_stride = d->o8_row_stride; a.o8_inv = d->o8_inv; a.g_act = d->g_activated;
   for (int s = 0; s < d->nseg && s < 4; ++s) {
     a.seg[s].K = (const bf16_t*)d->seg[s].K; a.seg[s].k_ld = d->seg[s].k_ld; a.seg[s].k_row_stride = d->seg[s].k_row_stride;
     a.seg[s].k_head_stride = d->seg[s].k_head_stride;

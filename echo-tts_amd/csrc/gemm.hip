@@ -297,6 +297,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
               }
             }
           }
+          if (sec == 3 && p.qkv_gate_act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(sigmoid_fast(y[i]));
+          }
           if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
         }
       }
@@ -1048,6 +1052,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           for (int jn = 0; jn < 8; ++jn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
+          if (sec == 3 && p.qkv_gate_act) {      // the attention epilogue's sigmoid, moved here (same operations on the same bf16 values)
+#pragma unroll
+            for (int jn = 0; jn < 8; ++jn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(sigmoid_fast(yv[jn][r]));
+          }
           float rs = 0.f;
           const float4* rp = nullptr;
           if (sec < 2) {

@@ -202,6 +202,8 @@ typedef struct {
    * c8 != NULL (fp8 + swiglu only): the SwiGLU output leaves as e4m3(bf16(out) * c8_inv) bytes at c8 (row pitch c8_ld bytes, % 8 == 0,
    * saturating at +-448) instead of bf16 at C - the A operand of the next fp8 GEMM without a quantisation pass */
   float a_scale_const; void* c8; int64_t c8_ld; float c8_inv;
+  int qkv_gate_act;              /* ABI 6, qkv_mode + bf16: the gate section is stored as bf16(sigmoid(bf16(acc))) (v_exp + v_rcp form) - the value the
+                                  * attention epilogue derives from a raw gate; pass echo_attn_desc.g_activated = 1 to the attention that reads it */
 } echo_gemm_desc;
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 /* In-place reformat of an fp32 weight matrix (rows x ld, ld % 32 == 0) for w_presplit: every aligned block of 32 floats becomes
@@ -229,6 +231,7 @@ typedef struct {
   /* ABI 6: O8 != NULL -> the (gated) output is written as e4m3(bf16(out) * o8_inv) bytes to O8 (same indexing as O, pitches in bytes,
    * o8_ld % 4 == 0, saturating) INSTEAD of bf16 to O: wo's fp8 operand under a static activation scale (echo_fp8_set_static_scales) */
   void* O8; int64_t o8_ld, o8_row_stride; float o8_inv;
+  int g_activated;               /* ABI 6: G already holds bf16(sigmoid(gate)) (echo_gemm_desc.qkv_gate_act): the epilogue only multiplies */
 } echo_attn_desc;
 int echo_op_attention_bf16(const echo_attn_desc* d, void* stream);
 

@@ -64,6 +64,7 @@ def gemm(A, W, C_out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, C
     if qkv is not None:       # fused QKV(G) tail: dict(D, S, rope_heads, pos0, eps, qk_w, rope, vt, vt_ld, vt_row_stride)
         d.qkv_mode, d.qkv_D, d.qkv_S, d.rope_heads, d.pos0, d.qk_eps = 1, qkv["D"], qkv["S"], qkv["rope_heads"], qkv.get("pos0", 0), qkv["eps"]
         d.qk_w, d.rope, d.vt, d.vt_ld, d.vt_row_stride = qkv["qk_w"].data_ptr(), qkv["rope"].data_ptr(), qkv["vt"].data_ptr(), qkv["vt_ld"], qkv["vt_row_stride"]
+        d.qkv_gate_act = int(qkv.get("gate_act", 0))
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     elif ksplit > 1:

@@ -215,6 +215,15 @@ def test_attention_bf16_joint_segments(S, Lt, Ls, use_bias, spike):
     assert float((err - refr.abs() * 2.0 ** -7).max()) < 3e-2, float(err.max())
     assert float(err.mean()) < 2e-3, float(err.mean())
     # e4m3 output (ABI 6, fp8 engine with a static activation scale): the same launch with O8 writes e4m3(bf16(out) * inv), saturating
+    # ABI 6, g_activated: the gate tensor already holds bf16(sigmoid(gate)) (what the QKVG tail stores with qkv_gate_act): same output up to
+    # the rounding of torch's sigmoid against the kernels' v_exp + v_rcp form
+    act = torch.sigmoid(gate.float()).bfloat16()
+    out_act = torch.zeros_like(out)
+    d.G, d.O, d.g_activated = act.data_ptr(), out_act.data_ptr(), 1
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    d.G, d.O, d.g_activated = gate.data_ptr(), out.data_ptr(), 0
+    U.bf16_close(out_act, out, ulps=2.0, atol=1e-6, frac_exact=0.98)
     _check_attention_fp8_output(d, out, R * S, H * 128, inv=448.0 / float(out.float().abs().max()) * 1.5)      # the largest values saturate at 448
 
 
@@ -559,6 +568,16 @@ def test_gemm_pingpong_fused_qkv_tail_multi_tile(rows, S):
     U.bf16_close(out[:, D:2 * D], k, ulps=2.0, atol=2.0 ** -4, frac_exact=0.99)
     assert torch.equal(out[:, 3 * D:], gte)
     assert torch.equal(vt[:, :, :S], v.view(rows, S, D).transpose(1, 2))
+    # ABI 6, qkv_gate_act: the gate section leaves as bf16(sigmoid(bf16(acc))) (the attention epilogue's v_exp + v_rcp form, moved into
+    # this tail), everything else bit for bit as before - the ping-pong kernel and the tile kernel's tail (cfg 4)
+    for cfg in (5, 4):
+        vt2 = torch.zeros_like(vt)
+        out2 = torch.zeros_like(out)
+        U.gemm(A, W, out2, M=M, N=4 * D, K=K, lda=K, ldw=K, ldc=4 * D, cfg=cfg,
+               qkv=dict(D=D, S=S, rope_heads=H // 2, pos0=3, eps=1e-5, qk_w=qk_w, rope=rope, vt=vt2, vt_ld=Sp, vt_row_stride=D * Sp, gate_act=1))
+        if cfg == 5:
+            assert torch.equal(out2[:, :3 * D], out[:, :3 * D]) and torch.equal(vt2, vt)
+        U.bf16_close(out2[:, 3 * D:], torch.sigmoid(gte.float()).bfloat16(), ulps=1.0, frac_exact=0.995)
 
 
 @pytest.mark.parametrize("cfg", [5, 4, 2, 0, 104, 106, 107])
