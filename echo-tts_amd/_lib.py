@@ -116,6 +116,7 @@ SIGNATURES = {
     "echo_sample_euler": (C.c_int, [vp, C.POINTER(EchoSamplerParams), vp, vp, vp]),
     "echo_dac_decode": (C.c_int, [vp, vp, C.c_int, C.c_float, vp, vp]),
     "echo_dac_decode_zq": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "echo_dac_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, c_i64, vp]),
     "echo_set_pca": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "echo_dac_hop": (C.c_int, [vp]),
     "echo_finalize_dac_encoder": (C.c_int, [vp, vp]),

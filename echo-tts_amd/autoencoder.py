@@ -5,6 +5,7 @@ ConvTranspose1d kernel into the GEMM form the HIP taps-GEMM consumes (channels-l
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -360,9 +361,13 @@ class DAC:
         lat = latent.to(self._device, torch.float32).contiguous()
         B, T, _ = lat.shape
         out = torch.empty((B, 1, T * self.config.hop), dtype=torch.float32, device=self._device)
-        for b in range(B):
-            L.check(self._lib.echo_dac_decode(self._ctx, lat[b].data_ptr(), T, self._latent_scale, out[b].data_ptr(),
-                                              self._stream()), self._ctx)
+        if os.environ.get("ECHO_DAC_BATCH", "1") == "0":      # A/B aid: one decode call per item (the round-1 path)
+            for b in range(B):
+                L.check(self._lib.echo_dac_decode(self._ctx, lat[b].data_ptr(), T, self._latent_scale, out[b].data_ptr(), self._stream()), self._ctx)
+            return out
+        # one call for the batch: PCA inverse + post_module transformer on the B * T stacked rows, the convolution stack per item
+        L.check(self._lib.echo_dac_decode_batch(self._ctx, lat.data_ptr(), B, T, self._latent_scale, out.data_ptr(), T * self.config.hop,
+                                                self._stream()), self._ctx)
         return out
 
     @torch.no_grad()

@@ -151,7 +151,7 @@ struct EngineBase {
   size_t gemm_events_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> attn_events;
   size_t attn_events_used = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
   virtual ~EngineBase() {
     for (auto& kv : raw) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -177,6 +177,7 @@ struct EngineBase {
   virtual int sample_euler(const echo_sampler_params* p, const float* x0, float* out, hipStream_t st) = 0;
   virtual int dac_decode(const float* lat, int T, float scale, float* wav, hipStream_t st) = 0;
   virtual int dac_decode_zq(const float* z, int T, float* wav, hipStream_t st) = 0;
+  virtual int dac_decode_batch(const float* lat, int B, int T, float scale, float* wav, long wav_stride, hipStream_t st) = 0;
   virtual int set_pca(const float* w, const float* mean, int on_device, hipStream_t st) = 0;
   virtual int finalize_dac_encoder(hipStream_t st) = 0;
   virtual int dac_encode(const float* audio, long n, float* lat, int32_t* codes, float* zq, hipStream_t st) = 0;
@@ -1520,40 +1521,46 @@ struct Engine : EngineBase {
 
   // WindowLimitedTransformer layers on channels-last x (Tn, C), in place; scratch: xn_buf, ao_buf (>= Tp*C + Tp*ff floats
   // and Tn*C floats).  autoencoder.py:786-802, 590-626, 663-717.  The final RMSNorm is applied by the caller.
+  // `B` items of `Tn` frames each, stacked as B * Tn rows: every row-wise GEMM / norm sees all rows at once (M = 15360 instead of 24 x 640
+  // for a bench call), the attention is per (item, head) through the two-level batch strides of the GEMM descriptor
   int dac_transformer(std::vector<DacLayer>& layers, float* x, int Tn, int C, int nh, int hd, int ff, int window, float* xn_buf,
-                      float* ao_buf, hipStream_t st) {
+                      float* ao_buf, hipStream_t st, int B = 1) {
     if (!ae_rope || Tn > ae_rope_npos) return fail("ae rope table missing or too short");
     if (hd != 64 || C != nh * hd || ff % 64) return fail("unsupported transformer sizes");
-    const int Tp = (int)rup(Tn, 128);
+    const int R = B * Tn;
+    const int Tp = (int)rup(R, 128);
     const long ldq = 3L * nh * hd;
     const int Tk = (int)rup(Tn, 32);
-    CK(b_dq.reserve((size_t)(Tp + 128) * ldq * sizeof(float)));
-    CK(b_dscore.reserve((size_t)nh * Tn * Tk * sizeof(float)));
-    CK(b_dvt.reserve((size_t)(nh + 1) * hd * rup(Tn, 64) * sizeof(float) + 128 * rup(Tn, 64) * sizeof(float)));
-    float *xn = xn_buf, *qkv = b_dq.as<float>(), *sc = b_dscore.as<float>(), *vt = b_dvt.as<float>(), *ao = ao_buf, *hh = xn_buf + (long)Tp * C;
     const int vld = (int)rup(Tn, 64);
+    const long vt_item = (long)nh * hd * vld;
+    CK(b_dq.reserve((size_t)(Tp + 128) * ldq * sizeof(float)));
+    CK(b_dscore.reserve((size_t)B * nh * Tn * Tk * sizeof(float)));
+    CK(b_dvt.reserve((size_t)(B * vt_item + (long)hd * vld + 128L * vld) * sizeof(float)));
+    float *xn = xn_buf, *qkv = b_dq.as<float>(), *sc = b_dscore.as<float>(), *vt = b_dvt.as<float>(), *ao = ao_buf, *hh = xn_buf + (long)Tp * C;
     for (auto& L : layers) {
-      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.an, nullptr, st));
-      CKI(frun(FG(xn, C, L.wqkv, C, qkv, ldq, Tn, 3 * nh * hd, C), st));
-      CK(launch_ae_rope(qkv, ldq, Tn, Tn, nh, hd, ae_rope, st));
-      CK(launch_ae_rope(qkv + nh * hd, ldq, Tn, Tn, nh, hd, ae_rope, st));
-      CK(launch_transpose_heads<float>(qkv + 2 * nh * hd, ldq, vt, vld, 0, 1, Tn, nh, hd, st));
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, R, C, cfg.dac_norm_eps, L.an, nullptr, st));
+      CKI(frun(FG(xn, C, L.wqkv, C, qkv, ldq, R, 3 * nh * hd, C), st));
+      CK(launch_ae_rope(qkv, ldq, R, Tn, nh, hd, ae_rope, st));
+      CK(launch_ae_rope(qkv + nh * hd, ldq, R, Tn, nh, hd, ae_rope, st));
+      CK(launch_transpose_heads<float>(qkv + 2 * nh * hd, ldq, vt, vld, vt_item, B, Tn, nh, hd, st));
       {
         GemmArgs g = FG(qkv, ldq, qkv + nh * hd, ldq, sc, Tk, Tn, Tk, hd);
-        g.nbatch = nh; g.nbi = nh; g.a_bi = hd; g.w_bi = hd; g.c_bi = (long)Tn * Tk;
+        g.nbatch = B * nh; g.nbi = nh;
+        g.a_bo = (long)Tn * ldq; g.a_bi = hd; g.w_bo = (long)Tn * ldq; g.w_bi = hd; g.c_bo = (long)nh * Tn * Tk; g.c_bi = (long)Tn * Tk;
         g.acc_scale = 1.0f / sqrtf((float)hd);
         CKI(frun(g, st));
       }
-      CK(launch_softmax_f32(sc, Tk, Tn, nh, Tn, Tk, nullptr, 0, 1, 1, window, st));
+      CK(launch_softmax_f32(sc, Tk, Tn, B * nh, Tn, Tk, nullptr, 0, 1, 1, window, st));
       {
         GemmArgs g = FG(sc, Tk, vt, vld, ao, C, Tn, hd, Tk);
-        g.nbatch = nh; g.nbi = nh; g.a_bi = (long)Tn * Tk; g.w_bi = (long)hd * vld; g.c_bi = hd;
+        g.nbatch = B * nh; g.nbi = nh;
+        g.a_bo = (long)nh * Tn * Tk; g.a_bi = (long)Tn * Tk; g.w_bo = vt_item; g.w_bi = (long)hd * vld; g.c_bo = (long)Tn * C; g.c_bi = hd;
         CKI(frun(g, st));
       }
-      { GemmArgs g = FG(ao, C, L.wo, nh * hd, x, C, Tn, C, nh * hd); g.colscale = L.ga; g.res = x; g.ldres = C; CKI(frun(g, st)); }
-      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, Tn, C, cfg.dac_norm_eps, L.fn, nullptr, st));
-      { GemmArgs g = FG(xn, C, L.w13, C, hh, ff, Tn, 2 * ff, C); g.swiglu = 1; CKI(frun(g, st)); }
-      { GemmArgs g = FG(hh, ff, L.w2, ff, x, C, Tn, C, ff); g.colscale = L.gf; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+      { GemmArgs g = FG(ao, C, L.wo, nh * hd, x, C, R, C, nh * hd); g.colscale = L.ga; g.res = x; g.ldres = C; CKI(frun(g, st)); }
+      CK(launch_norm<float>(NORM_AE_RMS, x, C, xn, C, R, C, cfg.dac_norm_eps, L.fn, nullptr, st));
+      { GemmArgs g = FG(xn, C, L.w13, C, hh, ff, R, 2 * ff, C); g.swiglu = 1; CKI(frun(g, st)); }
+      { GemmArgs g = FG(hh, ff, L.w2, ff, x, C, R, C, ff); g.colscale = L.gf; g.res = x; g.ldres = C; CKI(frun(g, st)); }
     }
     return ECHO_OK;
   }
@@ -1793,7 +1800,57 @@ struct Engine : EngineBase {
   }
 
   // lat: (T, latent) latents (PCA applied here)  OR  zq: (T, C) channels-last quantizer output
-  int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st, int f0 = 0) {
+  // ---- the front of the decoder (PCA inverse, post_module transformer, its final norm) for B items at once: B * Tn rows through every
+  // row-wise GEMM (a 24-item call: M = 15360 instead of 24 launches at M = 640 with split-K reductions), attention per (item, head).
+  // Writes the normalised frames of item b at b_dfn + b * Tn * C; dac_run(..., front = that pointer) then runs the convolutions.
+  DevBuf b_dfx, b_dfs, b_dfu, b_dfn;
+  float dac_front_ms = 0.f;         // profiling: the last batched front's time (dac_decode_batch divides it over its items)
+  int dac_front_batch(const float* lat, int B, int Tn, float latent_scale, hipStream_t st) {
+    if (!dac_ready) return fail("echo_finalize_dac was not called");
+    if (!pca_set) return fail("echo_set_pca was not called");
+    const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
+    const long R = (long)B * Tn, Tp = rup(R, 128);
+    CK(b_dfx.reserve((size_t)(Tp + 128) * C * sizeof(float)));
+    CK(b_dfs.reserve((size_t)(Tp + 128) * (C + ff) * sizeof(float)));
+    CK(b_dfu.reserve((size_t)(Tp + 128) * C * sizeof(float)));
+    CK(b_dfn.reserve((size_t)(Tp + 128) * C * sizeof(float)));
+    CK(b_dmisc.reserve((size_t)Tp * pca_kpad * sizeof(float)));
+    if (profiling) {
+      for (auto& e : ev) if (!e) CK(hipEventCreate(&e));
+      CK(hipEventRecord(ev[4], st));
+    }
+    float* x = b_dfx.as<float>();
+    CK(launch_pca_prep(lat, b_dmisc.as<float>(), pca_kpad, R, cfg.latent_size, pca_kpad, latent_scale, st));
+    {
+      GemmArgs g = FG(b_dmisc.as<float>(), pca_kpad, pca_w, pca_kpad, x, C, R, C, pca_kpad);
+      g.bias = pca_b;
+      CKI(frun(g, st));
+    }
+    CKI(dac_transformer(dpost, x, Tn, C, nh, hd, ff, cfg.dac_post_window, b_dfs.as<float>(), b_dfu.as<float>(), st, B));
+    CK(launch_norm<float>(NORM_AE_RMS, x, C, b_dfn.as<float>(), C, (int)R, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
+    if (profiling) {
+      CK(hipEventRecord(ev[5], st));
+      CK(hipEventSynchronize(ev[5]));
+      CK(hipEventElapsedTime(&dac_front_ms, ev[4], ev[5]));
+    }
+    return ECHO_OK;
+  }
+  int dac_decode_batch(const float* lat, int B, int Tn, float latent_scale, float* wav, long wav_stride, hipStream_t st) override {
+    if (B < 1 || Tn < 1) return fail("dac_decode_batch: empty batch");
+    if (B == 1) return dac_decode(lat, Tn, latent_scale, wav, st);
+    CKI(dac_front_batch(lat, B, Tn, latent_scale, st));
+    float ms = 0.f, ms_gemm = 0.f;
+    for (int b = 0; b < B; ++b) {
+      CKI(dac_run(nullptr, nullptr, Tn, 1.0f, wav + (long)b * wav_stride, st, 0, b_dfn.as<float>() + (long)b * Tn * cfg.dac_latent_dim));
+      ms += prof.ms_total; ms_gemm += prof.ms_gemm_sum;
+    }
+    if (profiling) {     // per-item averages incl. the shared front (the front's GEMM launches are not in ms_gemm_sum)
+      prof.ms_total = (ms + dac_front_ms) / B; prof.ms_steps = prof.ms_total; prof.ms_gemm_sum = ms_gemm / B;
+    }
+    return ECHO_OK;
+  }
+
+  int dac_run(const float* lat, const float* zq, int Tn, float latent_scale, float* wav, hipStream_t st, int f0 = 0, const float* front = nullptr) {
     if (!dac_ready) return fail("echo_finalize_dac was not called");
     if (!ae_rope || Tn > ae_rope_npos) return fail("ae rope table missing or too short");
     const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
@@ -1820,6 +1877,10 @@ struct Engine : EngineBase {
     const int Tp = (int)rup(Tn, 128);
     CK(b_dmisc.reserve((size_t)Tp * pca_kpad * sizeof(float)));
     float* x = bufY;
+    if (front) {
+      // the front already ran for the whole batch (dac_front_batch): this item's normalised frames go where the norm would put them
+      CK(hipMemcpyAsync(bufS, front, (size_t)Tn * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
     if (lat) {
       CK(launch_pca_prep(lat, b_dmisc.as<float>(), pca_kpad, Tn, cfg.latent_size, pca_kpad, latent_scale, st));
       GemmArgs g = FG(b_dmisc.as<float>(), pca_kpad, pca_w, pca_kpad, x, C, Tn, C, pca_kpad);
@@ -1831,6 +1892,7 @@ struct Engine : EngineBase {
     // ---- post_module: window-limited causal transformer (autoencoder.py:786-802)
     CKI(dac_transformer(dpost, x, Tn, C, nh, hd, ff, cfg.dac_post_window, bufS, bufU, st));
     CK(launch_norm<float>(NORM_AE_RMS, x, C, bufS, C, Tn, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
+    }
     // ---- quantizer.upsample: [ConvT k=f s=f ; ConvNeXt] (autoencoder.py:427-435, 360-373)
     // f0 > 0: only frames f0.. go through the convolutions; the first conv's causal taps then read the real frames in front
     // of f0 (still in bufS), every later one the zero rows in front of its buffer
@@ -2005,6 +2067,9 @@ int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* 
 }
 int echo_dac_decode(echo_ctx* ctx, const float* latent, int T, float latent_scale, float* wav_out, void* stream) {
   return ctx ? ctx->eng->dac_decode(latent, T, latent_scale, wav_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dac_decode_batch(echo_ctx* ctx, const float* latent, int B, int T, float latent_scale, float* wav_out, int64_t wav_stride, void* stream) {
+  return ctx ? ctx->eng->dac_decode_batch(latent, B, T, latent_scale, wav_out, (long)wav_stride, (hipStream_t)stream) : ECHO_ERR;
 }
 int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, void* stream) {
   return ctx ? ctx->eng->dac_decode_zq(z, T, wav_out, (hipStream_t)stream) : ECHO_ERR;

@@ -155,6 +155,10 @@ int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* 
 int echo_dac_decode(echo_ctx* ctx, const float* latent, int T, float latent_scale, float* wav_out, void* stream);
 /* autoencoder.py:1128-1132 DAC.decode_zq alone: z (T, dac_latent_dim) fp32 CHANNELS-LAST (= z_q[b].T) -> wav (T * hop). */
 int echo_dac_decode_zq(echo_ctx* ctx, const float* z, int T, float* wav_out, void* stream);
+/* ABI 6: B utterances of T frames each (latent: B x T x latent_size, contiguous) -> wav_out + b * wav_stride (floats).  Same result as B
+ * echo_dac_decode calls up to the fp32 summation order of the row-wise GEMMs: the PCA inverse, the post_module transformer and its norm
+ * run once on the B * T stacked rows (attention per item and head), the convolution stack per item.  inference.py:226-229 on a batch. */
+int echo_dac_decode_batch(echo_ctx* ctx, const float* latent, int B, int T, float latent_scale, float* wav_out, int64_t wav_stride, void* stream);
 /* Streaming decode (reference: every conv of autoencoder.py:264-331 is causal, gradio_app.py:43 decodes whole
  * utterances): latent (T, latent_size) fp32 are ALL frames generated so far; the window-limited post_module transformer
  * runs over all of them, the convolutional stack only over frames first_frame.. ; wav_out receives (T - first_frame) * 2048

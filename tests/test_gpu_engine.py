@@ -314,6 +314,31 @@ def test_dac_full_size_160_frames_against_oracle():
     assert got.shape == want.shape and e < WAV_TOL and e < 1e-3 * U.rms(want), (e, U.rms(want))
 
 
+@pytest.mark.parametrize("size, B, T", [("tiny", 3, 40), ("full", 5, 200)])
+def test_dac_decode_batch_equals_single_decodes(size, B, T):
+    """echo_dac_decode_batch (ABI 6; `DAC.decode_latent` on a batch): the PCA inverse, the post_module transformer and its norm run once on
+    the B * T stacked rows (window-128 causal attention per item and head: T = 200 crosses the window; the items must not see each
+    other), the convolution stack per item.  Every item must equal its own single decode up to the fp32 summation order of the row-wise
+    GEMMs (other M, other tile plan), and the batch call must be reproducible."""
+    cfg = TINY_DAC if size == "tiny" else R.DacConfig()
+    w = R.make_dac_weights(cfg, 0)
+    dac = E.DAC(cfg, w, device=DEV)
+    pca = R.make_pca(cfg, 80, 0)
+    st = E.PCAState(pca.pca_components, pca.pca_mean, pca.latent_scale)
+    lat = torch.randn((B, T, 80), generator=torch.Generator().manual_seed(11))
+    lat[1] *= 3.0                                            # items of different scale: a leak between items would show
+    allb = E.ae_decode(dac, st, lat)
+    again = E.ae_decode(dac, st, lat)
+    assert torch.equal(allb, again) and bool(torch.isfinite(allb).all())
+    worst = 0.0
+    for b in range(B):
+        one = E.ae_decode(dac, st, lat[b:b + 1])
+        e = rms(allb[b:b + 1], one)
+        worst = max(worst, e / max(U.rms(one), 1e-12))
+        assert e < 3e-5 * U.rms(one) + 1e-7, (b, e, U.rms(one))       # measured 6e-6 (full size): split-K / tile plans differ with M
+    print(f"DAC decode batch ({size}, {B} x {T} frames): worst relative rms difference to single decodes {worst:.2e}")
+
+
 def test_dac_is_causal_and_length_independent(golden):
     """Size-independent property: decoding a longer input reproduces the shorter one's samples."""
     cfg = TINY_DAC
