@@ -1802,18 +1802,24 @@ struct Engine : EngineBase {
   // lat: (T, latent) latents (PCA applied here)  OR  zq: (T, C) channels-last quantizer output
   // ---- the front of the decoder (PCA inverse, post_module transformer, its final norm) for B items at once: B * Tn rows through every
   // row-wise GEMM (a 24-item call: M = 15360 instead of 24 launches at M = 640 with split-K reductions), attention per (item, head).
-  // Writes the normalised frames of item b at b_dfn + b * Tn * C; dac_run(..., front = that pointer) then runs the convolutions.
+  // quantizer.upsample rides along; item b's upsampled rows end up at dac_front_out + b * dac_front_item_rows * C and
+  // dac_run(..., front = that pointer) runs the decoder convolutions on them.
   DevBuf b_dfx, b_dfs, b_dfu, b_dfn;
   float dac_front_ms = 0.f;         // profiling: the last batched front's time (dac_decode_batch divides it over its items)
+  float* dac_front_out = nullptr;   // item b's upsampled rows: dac_front_out + b * dac_front_item_rows * C
+  long dac_front_item_rows = 0;
   int dac_front_batch(const float* lat, int B, int Tn, float latent_scale, hipStream_t st) {
     if (!dac_ready) return fail("echo_finalize_dac was not called");
     if (!pca_set) return fail("echo_set_pca was not called");
     const int C = cfg.dac_latent_dim, nh = cfg.dac_post_heads, hd = cfg.dac_post_head_dim, ff = cfg.dac_post_ffn;
     const long R = (long)B * Tn, Tp = rup(R, 128);
-    CK(b_dfx.reserve((size_t)(Tp + 128) * C * sizeof(float)));
-    CK(b_dfs.reserve((size_t)(Tp + 128) * (C + ff) * sizeof(float)));
+    long upf = 1;
+    for (int i = 0; i < cfg.dac_n_up; ++i) upf *= cfg.dac_up_factors[i];
+    const long Rup = rup(R * upf, 128) + 128;       // rows after quantizer.upsample
+    CK(b_dfx.reserve((size_t)Rup * C * sizeof(float)));
+    CK(b_dfs.reserve((size_t)std::max((Tp + 128) * (long)(C + ff), Rup * 4L * C) * sizeof(float)));
     CK(b_dfu.reserve((size_t)(Tp + 128) * C * sizeof(float)));
-    CK(b_dfn.reserve((size_t)(Tp + 128) * C * sizeof(float)));
+    CK(b_dfn.reserve((size_t)Rup * C * sizeof(float)));
     CK(b_dmisc.reserve((size_t)Tp * pca_kpad * sizeof(float)));
     if (profiling) {
       for (auto& e : ev) if (!e) CK(hipEventCreate(&e));
@@ -1828,6 +1834,21 @@ struct Engine : EngineBase {
     }
     CKI(dac_transformer(dpost, x, Tn, C, nh, hd, ff, cfg.dac_post_window, b_dfs.as<float>(), b_dfu.as<float>(), st, B));
     CK(launch_norm<float>(NORM_AE_RMS, x, C, b_dfn.as<float>(), C, (int)R, C, cfg.dac_norm_eps, dpost_norm, nullptr, st));
+    // quantizer.upsample on the stacked rows as well (autoencoder.py:427-435, 360-373): the ConvTranspose is a 1-tap GEMM, the ConvNeXt's
+    // causal depthwise conv restarts its padding per item (dwconv_ln_kernel: position = row % rows_per_item), the rest is row-wise
+    {
+      float *cur = b_dfn.as<float>(), *other = x, *third = b_dfs.as<float>();
+      long rows = R, per_item = Tn;
+      for (auto& U : dups) {
+        { GemmArgs g = FG(cur, C, U.w, C, other, (long)U.f * C, rows, U.f * C, C); g.bias = U.b; g.vec_mod = C; CKI(frun(g, st)); }
+        rows *= U.f; per_item *= U.f;
+        CK(launch_dwconv_ln(other, C, cur, C, (int)rows, (int)per_item, C, U.dw, U.db, U.lnw, U.lnb, 1e-6f, st));
+        { GemmArgs g = FG(cur, C, U.p1w, C, third, 4L * C, rows, 4 * C, C); g.bias = U.p1b; g.act = 2; CKI(frun(g, st)); }
+        { GemmArgs g = FG(third, 4L * C, U.p2w, 4L * C, other, C, rows, C, 4 * C); g.bias = U.p2b; g.colscale = U.gamma; g.res = other; g.ldres = C; CKI(frun(g, st)); }
+        std::swap(cur, other);
+      }
+      dac_front_out = cur; dac_front_item_rows = per_item;
+    }
     if (profiling) {
       CK(hipEventRecord(ev[5], st));
       CK(hipEventSynchronize(ev[5]));
@@ -1841,7 +1862,7 @@ struct Engine : EngineBase {
     CKI(dac_front_batch(lat, B, Tn, latent_scale, st));
     float ms = 0.f, ms_gemm = 0.f;
     for (int b = 0; b < B; ++b) {
-      CKI(dac_run(nullptr, nullptr, Tn, 1.0f, wav + (long)b * wav_stride, st, 0, b_dfn.as<float>() + (long)b * Tn * cfg.dac_latent_dim));
+      CKI(dac_run(nullptr, nullptr, Tn, 1.0f, wav + (long)b * wav_stride, st, 0, dac_front_out + (long)b * dac_front_item_rows * cfg.dac_latent_dim));
       ms += prof.ms_total; ms_gemm += prof.ms_gemm_sum;
     }
     if (profiling) {     // per-item averages incl. the shared front (the front's GEMM launches are not in ms_gemm_sum)
@@ -1878,8 +1899,9 @@ struct Engine : EngineBase {
     CK(b_dmisc.reserve((size_t)Tp * pca_kpad * sizeof(float)));
     float* x = bufY;
     if (front) {
-      // the front already ran for the whole batch (dac_front_batch): this item's normalised frames go where the norm would put them
-      CK(hipMemcpyAsync(bufS, front, (size_t)Tn * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+      // the front (incl. quantizer.upsample) already ran for the whole batch (dac_front_batch): this item's rows go to its own buffer,
+      // whose zero rows in front are the causal padding of the first decoder conv
+      CK(hipMemcpyAsync(bufS, front, (size_t)Tn * upf * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
     if (lat) {
       CK(launch_pca_prep(lat, b_dmisc.as<float>(), pca_kpad, Tn, cfg.latent_size, pca_kpad, latent_scale, st));
@@ -1899,7 +1921,8 @@ struct Engine : EngineBase {
     float* cur = bufS + (long)f0 * C;      // (rows, C)
     float* other = bufY;
     float* third = bufU;
-    long rows = Tn - f0;
+    long rows = front ? (long)Tn * upf : Tn - f0;
+    if (!front)
     for (auto& U : dups) {
       { GemmArgs g = FG(cur, C, U.w, C, other, (long)U.f * C, rows, U.f * C, C); g.bias = U.b; g.vec_mod = C; CKI(frun(g, st)); }
       rows *= U.f;
