@@ -77,19 +77,18 @@ __device__ __forceinline__ unsigned long long stamp() {
 // key subset; the two halves of a query block are merged once through LDS after the loop.  Two co-resident waves per
 // SIMD let one wave's softmax VALU / LDS reads / DMA issue overlap the other's MFMAs, and every wave issues only 4 of
 // the tile's 32 LDS-DMA pieces.
+// One 128-query block (bxq) of (row, head); `smem` = K ring [2][16 KiB] | V ring [2][16 KiB] (+ merge area).  A device function so that
+// attn_kernel runs it for its own blockIdx and attn_redo_kernel for the blocks the fast kernels flagged; a wave that `return`s here has
+// only left this function.
 template <bool CAUSAL, bool BIAS, bool PROF>
-__global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
+__device__ __forceinline__ void attn_body(const AttnArgs& p, char* const smem, const int bxq, const int head, const int row, const long prof_wg) {
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long k_t0 = 0, k_r0 = 0, pa = 0, pb = 0;
   if (PROF) { k_t0 = __builtin_amdgcn_s_memtime(); k_r0 = __builtin_amdgcn_s_memrealtime(); }
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
-  // second pass behind attn4_kernel: only the 256-query blocks it flagged are done again here (with per-tile rescaling)
-  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.redo_nb + ((blockIdx.x + p.q_block0) >> (p.q128 ? 0 : 1))] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wid & 3, kh = wid >> 2;
-  const int row = blockIdx.z, head = blockIdx.y;
-  const int qbase = (blockIdx.x + p.q_block0) * QT;
+  const int qbase = bxq * QT;
   const int fr = lane & 31, fh = lane >> 5;
   const int q = qbase + qb * 32 + fr;
   const bool q_ok = q < p.S;
@@ -374,7 +373,7 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the rings are reused / the workgroup ends
   if (PROF && lane == 0) {
-    unsigned long long* dst = (unsigned long long*)p.prof + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wid) * 8;
+    unsigned long long* dst = (unsigned long long*)p.prof + (prof_wg * 8 + wid) * 8;
     dst[0] = pt[0]; dst[1] = pt[1]; dst[2] = pt[2]; dst[3] = pt[3]; dst[4] = pt[4];
     dst[5] = __builtin_amdgcn_s_memtime() - k_t0; dst[6] = __builtin_amdgcn_s_memrealtime() - k_r0; dst[7] = pt[7] | (pa << 20) | (pb << 40);   // up to the end of the tile loop
   }
@@ -438,6 +437,39 @@ __global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
       if (p.O8) store_o4_fp8(p.O8 + (long)row * p.o8_row_stride + (long)q * p.o8_ld + head * HD + col, y, p.o8_inv);
       else *(uint2*)(op + col) = Vec4<bf16_t>::pack(y);
     }
+}
+
+template <bool CAUSAL, bool BIAS, bool PROF>
+__global__ void __launch_bounds__(512, 2) attn_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [2][16 KiB] | V ring [2][16 KiB]
+  // (ECHO_ATTN_REDO_FULL=1, A/B aid: the second pass as a full grid behind this filter instead of attn_redo_kernel)
+  if (p.redo_filter && p.redo_filter[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.redo_nb + ((blockIdx.x + p.q_block0) >> (p.q128 ? 0 : 1))] == 0) return;
+  attn_body<CAUSAL, BIAS, PROF>(p, smem, blockIdx.x + p.q_block0, blockIdx.y, blockIdx.z, ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// Second pass behind attn4_kernel / attn5_kernel: the blocks whose scores left the fast kernels' range (normally none) are done again
+// with per-tile rescaling.  A handful of workgroups, each scanning its share of the report words in one coalesced read and leaving at
+// once when none is set: as a full attn_kernel grid behind a filter, the pass put one 8-wave, 100 KiB-LDS workgroup per block (2 880 for a
+// CFG step of 24 utterances) into the queue behind every attention launch - 14-32 us each on the stream's critical path when the
+// other stream's GEMM holds the CUs (1.3 % of the kernel time of profiles/r02_bench_kernel_stats_v8.csv).
+__global__ void __launch_bounds__(512, 2) attn_redo_kernel(const AttnArgs p, const int nwords, const int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int base = blockIdx.x * per_wg;
+  const int n = min(per_wg, nwords - base);
+  int flag = 0;
+  for (int i = threadIdx.x; i < n; i += 512) flag |= p.redo_filter[base + i];
+  if (!__syncthreads_or(flag)) return;
+  const int nsub = p.q128 ? 1 : 2;            // a report word covers one 128-query block, or the two of a 256-query workgroup
+  for (int i = 0; i < n; ++i) {
+    if (p.redo_filter[base + i] == 0) continue;          // workgroup-uniform
+    const int w = base + i, blk = w % p.redo_nb, rh = w / p.redo_nb;
+    for (int sb = 0; sb < nsub; ++sb) {
+      const int bxq = blk * nsub + sb;
+      if (bxq * QT >= p.S) break;
+      attn_body<false, false, false>(p, smem, bxq, rh % p.H, rh / p.H, 0);
+      __syncthreads();                                   // the rings and the merge area are reused by the next block
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1460,7 +1492,16 @@ hipError_t launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     }
     b.q_block0 = 0;                              // second pass over the fast kernels' blocks: only the flagged ones do anything
     b.redo_filter = a.redo;
-    hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(min((int)grid.x, q128m ? nfast : 2 * nfast), a.H, a.rows), dim3(512), SMEM, st, b);
+    static const bool redo_full = getenv("ECHO_ATTN_REDO_FULL") && atoi(getenv("ECHO_ATTN_REDO_FULL")) != 0;
+    if (redo_full) {
+      hipLaunchKernelGGL((attn_kernel<false, false, false>), dim3(min((int)grid.x, q128m ? nfast : 2 * nfast), a.H, a.rows), dim3(512), SMEM, st, b);
+    } else {
+      static std::atomic<unsigned long long> prep_redo{0};
+      if (hipError_t e = ensure_dyn_lds((const void*)attn_redo_kernel, SMEM, prep_redo); e != hipSuccess) return e;
+      const int nwords = a.rows * a.H * nb256;
+      const int nwg = nwords < 32 ? nwords : 32;
+      hipLaunchKernelGGL(attn_redo_kernel, dim3(nwg), dim3(512), SMEM, st, b, nwords, (nwords + nwg - 1) / nwg);
+    }
     return hipGetLastError();
   }
   AttnArgs a0 = a;
