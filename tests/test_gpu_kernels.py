@@ -282,6 +282,66 @@ def test_attention_fp8_output_two_stream_blocks():
     _check_attention_fp8_output(d, out, R * S, D, inv=448.0 / float(out.float().abs().max()) * 1.5)
 
 
+def test_attention_range_fallback_many_blocks():
+    """attn_redo_kernel with several report words per workgroup: 6 rows x 16 heads x 2 blocks of 256 queries = 192 words over 32 workgroups
+    (6 each).  Keys whose score with one query is 20 x |q|^2 are planted so that flagged words share a scan chunk, sit in its first and
+    last word, cover a full 256-query block (two 128-query passes of attn_kernel's body) and the short last block; every query of the
+    flagged (row, head) pairs and of two untouched ones is checked against fp32."""
+    R, S, H, Lt = 6, 320, 16, 70
+    D = H * 128
+    qkvg = rnd(R * S + 256, 4 * D, dtype=torch.bfloat16, scale=0.5)
+    pS, pT = (S + 63) // 64 * 64, (Lt + 63) // 64 * 64
+    v_self = rnd(R, S, H, 128, dtype=torch.bfloat16, seed=1)
+    vt_self = v_self.permute(0, 2, 3, 1).contiguous()
+    vt_self = torch.nn.functional.pad(vt_self, (0, pS - S)).contiguous()
+    kt, v_t = rnd(Lt + 128, 4 * D, dtype=torch.bfloat16, seed=2), rnd(1, Lt, H, 128, dtype=torch.bfloat16, seed=3)
+    vt_t = torch.nn.functional.pad(v_t.permute(0, 2, 3, 1).contiguous(), (0, pT - Lt)).contiguous()
+    # (row, head, query, key position): words (row * 16 + head) * 2 + block; words 0 and 5 share workgroup 0's chunk, word 191 is the last
+    plants = [(0, 0, 7, 150), (0, 2, 300, 310), (0, 2, 40, 100), (3, 7, 200, 20), (5, 15, 319, 318)]
+    qv = qkvg[:R * S].view(R, S, 4 * D)
+    for (r, h, qi, kj) in plants:
+        qv[r, kj, D + h * 128:D + (h + 1) * 128] = (20.0 * qv[r, qi, h * 128:(h + 1) * 128].float()).bfloat16()
+    tx = [Lt, 0, Lt, Lt, 0, Lt]
+    nk = torch.tensor([[S] * R, tx], dtype=torch.int32, device=DEV)
+    out = torch.zeros((R * S, D), dtype=torch.bfloat16, device=DEV)
+    d = L.EchoAttnDesc()
+    d.Q, d.q_ld, d.q_row_stride = qkvg.data_ptr(), 4 * D, S * 4 * D
+    d.O, d.o_ld, d.o_row_stride = out.data_ptr(), D, S * D
+    d.S, d.H, d.rows, d.nseg, d.causal, d.scale = S, H, R, 2, 0, 1 / math.sqrt(128)
+    for i, (kp, kld, krs, vt, pitch, shared) in enumerate(((qkvg.data_ptr() + D * 2, 4 * D, S * 4 * D, vt_self, pS, False),
+                                                           (kt.data_ptr(), 4 * D, 0, vt_t, pT, True))):
+        sg = d.seg[i]
+        sg.K, sg.k_ld, sg.k_head_stride, sg.k_row_stride = kp, kld, 128, krs
+        sg.Vt, sg.vt_ld, sg.vt_head_stride = vt.data_ptr(), pitch, 128 * pitch
+        sg.vt_row_stride = 0 if shared else H * 128 * pitch
+        sg.nkeys = nk[i].data_ptr()
+        sg.kv_mod = 1 if shared else 0
+    redo = torch.zeros((R * H * ((S + 127) // 128),), dtype=torch.int32, device=DEV)
+    d.redo = redo.data_ptr()
+    L.check(U.lib().echo_op_attention_bf16(C.byref(d), U.stream()))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    import os
+    if os.environ.get("ECHO_ATTN", "5") in ("4", "5"):
+        words = redo[:R * H * 2].view(R, H, 2)        # the fast kernels' report: one word per 256-query block
+        flagged = {(r, h, qi // 256) for (r, h, qi, _) in plants}
+        assert {tuple(int(x) for x in ix) for ix in torch.nonzero(words).tolist()} == flagged, torch.nonzero(words).tolist()
+    for (r, h) in sorted({(r, h) for (r, h, _, _) in plants} | {(1, 3), (4, 9)}):
+        q = qv[r, :, h * 128:(h + 1) * 128].float()
+        k = qv[r, :, D + h * 128:D + (h + 1) * 128].float()
+        v = v_self[r, :, h].float()
+        if tx[r]:
+            k = torch.cat([k, kt[:Lt, h * 128:(h + 1) * 128].float()])
+            v = torch.cat([v, v_t[0, :, h].float()])
+        ref = torch.softmax(q @ k.T / math.sqrt(128), -1) @ v
+        got = out.view(R, S, D)[r, :, h * 128:(h + 1) * 128].float()
+        err = (got - ref).abs()
+        assert float((err - ref.abs() * 2.0 ** -7).max()) < 3e-2 and float(err.mean()) < 2e-3, (r, h, float(err.max()), float(err.mean()))
+    for (r, h, qi, kj) in plants:      # the planted key dominates its query: the output row is that key's value row
+        got = out.view(R, S, D)[r, qi, h * 128:(h + 1) * 128].float()
+        assert float((got - v_self[r, kj, h].float()).abs().max()) < 2e-2, (r, h, qi)
+
+
 @pytest.mark.parametrize("variant", ["1", "4", "5"])
 def test_attention_fast_kernel_variant(variant):
     """attn_kernel / attn4_kernel / attn5_kernel forced (ECHO_ATTN=1 / 4 / 5, read once per process; the default picks by grid size): the
@@ -292,7 +352,7 @@ def test_attention_fast_kernel_variant(variant):
     env = dict(os.environ, ECHO_ATTN=variant)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "joint_segments or deterministic_at_full_size or attention_tile_count_classes"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                        "joint_segments or deterministic_at_full_size or attention_tile_count_classes or range_fallback_many"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
