@@ -205,7 +205,7 @@ def main() -> None:
                     help="independent utterances in flight per GPU (one HIP stream + one engine context each); a step is then "
                          "`concurrency` utterances")
     ap.add_argument("--batch", type=int, default=24,
-                    help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows")
+                    help="utterances per sampler call (the reference's batch axis B): M = 3*B*640 / B*640 GEMM rows; at most 32 (the engine holds 96 rows per call)")
     ap.add_argument("--c5", action="store_true",
                     help="BASELINE config C5 instead of C2: fp8 (e4m3) operands for the EchoDiT block GEMMs, 100 Euler steps "
                          "(50 CFG x3 rows + 50 x1 row); the JSON line then says dtype fp8 and names C5 in config.workload")
