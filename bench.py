@@ -69,6 +69,23 @@ def dit_gemm_flops(batch: int = 1, steps: int = STEPS) -> float:
     return float(batch * rows * per_row + mod)
 
 
+def pp_algorithmic_bytes_per_launch(batch: int, steps: int = STEPS, fp8: bool = False) -> float:
+    """Algorithmic HBM bytes of an average gemm_pp_kernel launch of one sampler call (A and W read once, C written once, the residual of
+    wo / w2 read once): QKVG (N 8192, K 2048), wo (2048, 2048), w1||w3 (N 11776 -> 5888 columns out, K 2048), w2 (2048, K 5888) at
+    M = 3 * batch * 640 rows in the CFG steps and batch * 640 in the others; bf16 (fp8: 1-byte A / W operands)."""
+    D, F = 2048, 5888
+    ab = 1 if fp8 else 2
+
+    def layer(M):
+        qkvg = M * D * ab + 4 * D * D * ab + M * 4 * D * 2
+        wo = M * D * ab + D * D * ab + 2 * M * D * 2
+        w13 = M * D * ab + 2 * F * D * ab + M * F * 2
+        w2 = M * F * ab + D * F * ab + 2 * M * D * 2
+        return qkvg + wo + w13 + w2
+    n3, n1 = steps // 2, steps - steps // 2
+    return (n3 * layer(3 * batch * S) + n1 * layer(batch * S)) / (4.0 * (n3 + n1))
+
+
 def build(device, rank: int, world: int, concurrency: int = 1, batch: int = 1, fp8: bool = False, keep_state: bool = False):
     import echo_tts_amd as E
     from echo_tts_amd import parallel as P
@@ -303,6 +320,8 @@ def main() -> None:
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (" + ("fp8-e4m3" if args.c5 else "bf16") + " 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(pp_algorithmic_bytes_per_launch(nb, n_steps, args.c5)),
+                    "traffic_over_algorithmic": round(traffic / pp_algorithmic_bytes_per_launch(nb, n_steps, args.c5), 2) if traffic else None,
                     "launches": pr.n_pp, "avg_launch_us": round(1e3 * pr.ms_pp_sum / max(pr.n_pp, 1), 2),
                     "flops_per_launch": pr.flops_pp / max(pr.n_pp, 1),
                     "power_envelope": None if args.c5 else {
