@@ -12,6 +12,11 @@ timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write profiles/r02_pmc_gemm.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- $PMC_CMD (two separate passes; default batch 24, 2 streams)"
 cp profiles/r02_pmc_gemm.json $O/r02_pmc_gemm.json
 rm -rf $O/pmc_fetch $O/pmc_write
+# 1b. MFMA-pipe utilisation and effective clock per kernel family (one more counter pass, no tracing domains besides the kernel trace)
+timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o run -- $PMC_CMD > $O/pmc_mfma.log 2>&1
+python3 tools/summarize_pmc_mfma.py $O/pmc_mfma profiles/r02_pmc_mfma.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- $PMC_CMD (default batch 24, 2 streams)"
+cp profiles/r02_pmc_mfma.json $O/r02_pmc_mfma.json
+rm -rf $O/pmc_mfma
 # 2. tests + smoke
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
 tail -2 $O/gpu_tests.log
