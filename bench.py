@@ -317,6 +317,14 @@ def main() -> None:
             traffic, traffic_src = round(pm["traffic_bytes_per_launch"]), f"profiles/{pmf} (2 x FETCH_SIZE + WRITE_SIZE, KiB; rocprofv3 --pmc passes of this command at the default batch)"
         except Exception:
             pass
+        pmc_mfma = None
+        try:   # MFMA-pipe utilisation and effective clock of the same kernel from the committed rocprofv3 --pmc pass (tools/summarize_pmc_mfma.py)
+            if not args.c5:
+                k = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")))["kernels"]["gemm_pp_kernel"]
+                pmc_mfma = {"mfma_utilisation": round(k["mfma_utilisation"], 4), "effective_clock_ghz": round(k["effective_clock_ghz"], 3),
+                            "source": "profiles/r02_pmc_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); utilisation x clock / 2.4 GHz ~ frac)"}
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (" + ("fp8-e4m3" if args.c5 else "bf16") + " 256x256 ping-pong GEMM: QKVG / wo / SwiGLU / w2 of every EchoDiT block)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
@@ -324,6 +332,7 @@ def main() -> None:
                     "traffic_over_algorithmic": round(traffic / pp_algorithmic_bytes_per_launch(nb, n_steps, args.c5), 2) if traffic else None,
                     "launches": pr.n_pp, "avg_launch_us": round(1e3 * pr.ms_pp_sum / max(pr.n_pp, 1), 2),
                     "flops_per_launch": pr.flops_pp / max(pr.n_pp, 1),
+                    "pmc_mfma": pmc_mfma,
                     "power_envelope": None if args.c5 else {
                         "sustained_mfma_peak": SUSTAINED_BF16_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_BF16_TFLOPS, 4),
                         "note": "v_mfma_f32_32x32x16_bf16 issued back to back from registers on every SIMD (no LDS, no memory) sustains 1770 TFLOP/s on "
