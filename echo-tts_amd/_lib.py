@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ECHO_LIB_PATH") or os.path.join(HERE, "libechohip.so")   # override: debugging builds only
 
 ECHO_F32, ECHO_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i64 = C.c_int64
 vp = C.c_void_p
@@ -49,7 +49,7 @@ class EchoStep(C.Structure):
 
 class EchoSamplerParams(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("num_steps", C.c_int), ("start_pos", C.c_int), ("use_latent", C.c_int),
-                ("cfg_scale_text", C.c_float), ("cfg_scale_speaker", C.c_float), ("init_scale", C.c_float),
+                ("cfg_scale_text", C.c_float), ("cfg_scale_speaker", C.c_float), ("has_truncation", C.c_int), ("init_scale", C.c_float),
                 ("kv_scale", C.c_float), ("kv_max_layers", C.c_int),
                 ("steps", C.POINTER(EchoStep)), ("temb", vp)]
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "echo_scale_speaker_kv": (C.c_int, [vp, C.c_float, C.c_int, vp]),
     "echo_dit_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), vp, vp]),
+    "echo_dit_forward_t": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, vp]),
     "echo_sample_euler": (C.c_int, [vp, C.POINTER(EchoSamplerParams), vp, vp, vp]),
     "echo_dac_decode": (C.c_int, [vp, vp, C.c_int, C.c_float, vp, vp]),
     "echo_dac_decode_zq": (C.c_int, [vp, vp, C.c_int, vp, vp]),
@@ -124,6 +126,7 @@ SIGNATURES = {
     "echo_set_pca_encode": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, vp]),
     "echo_op_gemm": (C.c_int, [C.c_int, C.POINTER(EchoGemmDesc), vp]),
     "echo_op_quant_rows_fp8": (C.c_int, [vp, c_i64, vp, c_i64, vp, C.c_int, C.c_int, vp]),
+    "echo_op_norm_adaln_fp8": (C.c_int, [vp, c_i64, vp, c_i64, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "echo_op_presplit_weights": (C.c_int, [vp, c_i64, c_i64, vp]),
     "echo_op_pack_rows": (C.c_int, [vp, C.c_int, c_i64, vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_op_attention_bf16": (C.c_int, [C.POINTER(EchoAttnDesc), vp]),
@@ -132,6 +135,7 @@ SIGNATURES = {
                                         C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "echo_op_transpose_heads": (C.c_int, [C.c_int, vp, c_i64, vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_debug_get_kv": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "echo_debug_corrupt_tile": (C.c_int, [vp, C.c_int]),
     "echo_voice_capture": (C.c_int, [vp, C.POINTER(vp), vp]),
     "echo_voice_bind": (C.c_int, [vp, vp, vp]),
     "echo_voice_bytes": (c_i64, [vp]),

@@ -113,6 +113,16 @@ __global__ void build_bias_kernel(float* __restrict__ dst, long ld, int rows, in
   dst[(long)r * ld + c] = v;
 }
 
+// test instrument (echo_debug_corrupt_tile): C[r][c] = -C[r][c] on one tile
+template <typename T>
+__global__ void negate_tile_kernel(T* __restrict__ c, long ldc, int r0, int nr, int c0, int nc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nr * nc) return;
+  const long r = r0 + i / nc;
+  const int col = c0 + (int)(i % nc);
+  c[r * ldc + col] = Num<T>::st(-Num<T>::ld(c[r * ldc + col]));
+}
+
 // y = T(T(o) * T(sigmoid(g)))  (model.py:157,264) for the unfused fp32 path
 template <typename T>
 __global__ void gate_mul_kernel(T* __restrict__ o, long ldo, const T* __restrict__ g, long ldg, long rows, int cols) {
@@ -172,7 +182,7 @@ struct EngineBase {
   virtual int encode_speaker(const void* lat, const float* bias, const int32_t* nk, int B, int Ts, hipStream_t st) = 0;
   virtual int encode_latent(const void* lat, int B, int n, long row_stride, hipStream_t st) = 0;
   virtual int scale_speaker_kv(float s, int max_layers, hipStream_t st) = 0;
-  virtual int dit_forward(const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
+  virtual int dit_forward(const void* x, const void* temb, int n_t, const int32_t* row_t, int rows, int B, int S, int start_pos, int use_latent,
                           const int32_t* ton, const int32_t* son, float* v, hipStream_t st) = 0;
   virtual int sample_euler(const echo_sampler_params* p, const float* x0, float* out, hipStream_t st) = 0;
   virtual int dac_decode(const float* lat, int T, float scale, float* wav, hipStream_t st) = 0;
@@ -183,6 +193,7 @@ struct EngineBase {
   virtual int dac_encode(const float* audio, long n, float* lat, int32_t* codes, float* zq, hipStream_t st) = 0;
   virtual int set_pca_encode(const float* w, const float* bias, float scale, int on_device, hipStream_t st) = 0;
   virtual int debug_get_kv(int which, int layer, float* k, float* v, int* B, int* T) = 0;
+  int corrupt_countdown = 0;      // echo_debug_corrupt_tile
   virtual int voice_capture(struct VoiceSnap** out, hipStream_t st) = 0;
   virtual int voice_bind(const struct VoiceSnap* v, hipStream_t st) = 0;
   virtual int dac_decode_tail(const float* lat, int T, int f0, float scale, float* wav, hipStream_t st) = 0;
@@ -345,7 +356,11 @@ struct Engine : EngineBase {
     g.A = b_q8.p; g.lda = g.K; g.W = qw; g.ldw = g.K; g.fp8 = 1; g.a_scale = b_qs.as<float>(); g.w_scale = sw;
     return ECHO_OK;
   }
-  bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : true;
+  // Timing-based plan tuning is a TOOL, not a serving-path feature: it runs only when a plan table is being produced
+  // (ECHO_GEMM_PLANS_SAVE names the file to append to) or when ECHO_GEMM_TUNE=1 asks for it.  By default a shape the shipped table
+  // does not list takes the fixed rule below: no first-use stall under the global plan mutex, no 512 MiB cache flushes, and the
+  // summation order - the output bits of a seed - is the same in every process and on every box.
+  bool tune_enabled = getenv("ECHO_GEMM_TUNE") ? atoi(getenv("ECHO_GEMM_TUNE")) != 0 : getenv("ECHO_GEMM_PLANS_SAVE") != nullptr;
 
   template <typename U>
   int plan_gemm(GemmArgs& g, hipStream_t st) {
@@ -368,13 +383,20 @@ struct Engine : EngineBase {
       if (it == plans.end()) {
       const long t128 = (long)((g.M + 127) / 128) * (g.Npad / 128);
       if (!tune_enabled) {
-        // ECHO_GEMM_TUNE=0: fixed rules instead of timings (reproducible without a plan file): the ping-pong kernel for
-        // the big bf16 linears, 256-row tiles for long-M fp32 convolutions, 128x128 otherwise
+        // fixed rules instead of timings (what the shipped table's entries have in common): the ping-pong kernel for the big bf16
+        // linears, 256-row / 192- / 96-column tiles for long-M fp32 convolutions, 128x128 otherwise - with a split-K factor that
+        // brings a small grid towards one round of the 256 CUs while every split keeps at least 4 K steps
         const bool big = (long)g.M * g.Npad >= 256L * 256 * 64;
         if (sizeof(U) == 2 && big && g.nbatch == 1 && g.taps == 1 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (!g.swiglu || (g.N & 15) == 0) &&
             !g.snake_alpha && !g.C2 && g.act != 2 && g.store_main && (!g.qkv_mode || g.qkv_D % 256 == 0) && (!g.res || (g.ldres & 7) == 0) &&
             (g.vec_mod & 7) == 0) best.cfg = 5;
         else if (big && !g.qkv_mode) best.cfg = g.N % 192 == 0 && g.N % 256 != 0 ? 8 : g.N % 96 == 0 && g.N % 128 != 0 ? 9 : 2;
+        else if (g.nbatch == 1 && !g.qkv_mode && t128 <= 128) {
+          static const int kKs[] = {8, 6, 4, 3, 2};
+          for (int ks : kKs)
+            if (t128 * ks <= 256 && nk / ks >= 4) { best.ksplit = ks; break; }
+          if (nk >= 8) best.cfg = 1;     // deeper LDS pipeline for latency-bound small grids
+        }
       } else
       if ((long)g.M * g.N * g.K * g.taps >= (1L << 26)) {
         // time every candidate on the real operands with a scratch output (the tail is irrelevant for the ranking)
@@ -439,10 +461,21 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
 
-  int run(const GemmArgs& g_in, hipStream_t st) {
-    GemmArgs g = g_in;
-    if (g.fp8) { g.cfg = 5; g.ksplit = 1; }   // e4m3 operands exist for the ping-pong kernel only
-    else CKI(plan_gemm<T>(g, st));
+  // A plan comes from a table keyed by (M N K taps swiglu nbatch esize qkv split3); the tail features of a launch (residual, second
+  // output, Snake, activation, leading dimensions) are not part of the key, so a listed plan can be one this launch cannot take:
+  // the launcher refuses it with hipErrorInvalidValue and the generic 128 x 128 tile runs instead - on every path (profiling or
+  // not, bf16 / fp32 engine and the DAC's frun).
+  template <typename U>
+  hipError_t launch_planned(GemmArgs& g, hipStream_t st) {
+    hipError_t le = launch_gemm_nt<U>(g, st);
+    if (le == hipErrorInvalidValue && !g.fp8 && (g.cfg != 0 || g.ksplit > 1)) {
+      g.cfg = 0; g.ksplit = 1;
+      le = launch_gemm_nt<U>(g, st);
+    }
+    return le;
+  }
+  template <typename U>
+  int run_planned(GemmArgs& g, hipStream_t st, bool count_pp) {
     if (profiling) {
       if (gemm_events_used == gemm_events.size()) {
         hipEvent_t a, b;
@@ -450,24 +483,27 @@ struct Engine : EngineBase {
         gemm_events.emplace_back(a, b);
       }
       if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
-      gemm_event_flops[gemm_events_used] = g.cfg == 5 ? 2.0 * g.M * g.N * g.K * g.taps * g.nbatch : 0.0;
       if (gemm_event_shape.size() < gemm_events.size()) gemm_event_shape.resize(gemm_events.size());
-      gemm_event_shape[gemm_events_used] = {g.M, g.N, g.K, g.taps, g.swiglu, g.qkv_mode, g.fp8, g.cfg, g.ksplit, g.nbatch};
-      auto& e = gemm_events[gemm_events_used++];
+      const size_t slot = gemm_events_used++;
+      auto& e = gemm_events[slot];
       CK(hipEventRecord(e.first, st));
-      CK(launch_gemm_nt<T>(g, st));
+      CK(launch_planned<U>(g, st));
       CK(hipEventRecord(e.second, st));
+      gemm_event_flops[slot] = (count_pp && g.cfg == 5) ? 2.0 * g.M * g.N * g.K * g.taps * g.nbatch : 0.0;   // after the launch: g.cfg is what ran
+      gemm_event_shape[slot] = {g.M, g.N, g.K, g.taps, g.swiglu, g.qkv_mode, g.fp8, g.cfg, g.ksplit, g.nbatch};
       return ECHO_OK;
     }
-    {
-      hipError_t le = launch_gemm_nt<T>(g, st);
-      if (le == hipErrorInvalidValue && !g.fp8 && (g.cfg != 0 || g.ksplit > 1)) {   // a listed plan this launch's tail cannot take
-        g.cfg = 0; g.ksplit = 1;
-        le = launch_gemm_nt<T>(g, st);
-      }
-      CK(le);
-    }
+    CK(launch_planned<U>(g, st));
+    if (corrupt_countdown > 0 && g.cfg == 5 && !g.qkv_mode && !g.swiglu && !g.c8 && g.nbatch == 1 && g.M >= 512 && g.N >= 512 && --corrupt_countdown == 0)
+      hipLaunchKernelGGL(negate_tile_kernel<U>, dim3(256), dim3(256), 0, st, (U*)g.C, g.ldc, 256, 256, 256, 256);
     return ECHO_OK;
+  }
+
+  int run(const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
+    if (g.fp8) { g.cfg = 5; g.ksplit = 1; }   // e4m3 operands exist for the ping-pong kernel only
+    else CKI(plan_gemm<T>(g, st));
+    return run_planned<T>(g, st, true);
   }
 
   // ------------------------------------------------------------------ finalize: pack EchoDiT (SURVEY.md §A.5 names)
@@ -1089,8 +1125,17 @@ struct Engine : EngineBase {
     }
   }
 
-  // xin (rows*S, lat_pad) -> vout (rows*S, 128); modrow = this step's [2L][3][D] modulation table
-  int forward_rows(int rows, int B, int S, int start_pos, bool use_latent, const T* modrow, hipStream_t st) {
+  // Rows [row0, row0 + nrows) of one forward share the timestep whose modulation table is `mod` ([2L][3][D]).  The sampler's forwards are
+  // one segment; EchoDiT.forward with per-row timesteps (model.py:563-604 takes any t (R,)) is one segment per run of equal t.  Only the
+  // launches that read the modulation (the two AdaLN norms and the gated-residual tails of wo / w2) are issued per segment, on row
+  // sub-ranges of the same buffers; the t-independent ones (QKVG, attention, w1|w3) stay one launch over all rows.
+  struct ModSeg { int row0, nrows; const T* mod; };
+
+  // xin (rows*S, lat_pad) -> vout (rows*S, 128); modrow = this step's [2L][3][D] modulation table (or `segs`: per-row-range tables)
+  int forward_rows(int rows, int B, int S, int start_pos, bool use_latent, const T* modrow, hipStream_t st,
+                   const std::vector<ModSeg>* segs_in = nullptr) {
+    const std::vector<ModSeg> one = {ModSeg{0, rows, modrow}};
+    const std::vector<ModSeg>& segs = segs_in ? *segs_in : one;
     const int D = cfg.model_size, L = cfg.num_layers, H = cfg.num_heads, F = cfg.intermediate_size, M = rows * S;
     const int Sp = (int)rup(S, 64);
     T *xin = b_xin.as<T>(), *x = b_x.as<T>(), *xn = b_xn.as<T>(), *qkvg = b_qkvg.as<T>(), *vts = b_vt_self.as<T>(),
@@ -1111,16 +1156,17 @@ struct Engine : EngineBase {
     static const bool gate_act_on = getenv("ECHO_GATE_ACT") ? atoi(getenv("ECHO_GATE_ACT")) != 0 : true;     // 0: sigmoid in the attention epilogue (A/B aid)
     const int gate_act = (Num<T>::is_bf16 && D % 256 == 0 && gate_act_on) ? 1 : 0;
     for (int l = 0; l < L; ++l) {
-      const T* ma = modrow + (long)(2 * l) * 3 * D;
-      const T* mm = modrow + (long)(2 * l + 1) * 3 * D;
+      const long mao = (long)(2 * l) * 3 * D, mmo = (long)(2 * l + 1) * 3 * D;     // offsets of this layer's attention / mlp modulation in a table
       // fp8 engine: the AdaLN output goes straight to e4m3 rows (b_q8 / b_qs) when the following GEMM takes fp8 operands
       const bool nq1 = fp8 && D % 256 == 0 && q_wqkvg[l] != nullptr && D <= 4096;
       const bool nq2 = fp8 && q_w13[l] != nullptr && D <= 4096;
-      if (nq1) {
-        CKI(fp8_reserve(M, std::max(D, F)));
-        CK(launch_norm_adaln_fp8(x, D, b_q8.p, D, b_qs.as<float>(), M, D, cfg.norm_eps, ma + D, ma, st));
-      } else {
-        CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, ma + D, ma, st));
+      if (nq1) CKI(fp8_reserve(M, std::max(D, F)));
+      for (const ModSeg& sgm : segs) {
+        const long off = (long)sgm.row0 * S;
+        const int Ms = sgm.nrows * S;
+        const T* ma = sgm.mod + mao;
+        if (nq1) CK(launch_norm_adaln_fp8(x + off * D, D, b_q8.as<uint8_t>() + off * D, D, b_qs.as<float>() + off, Ms, D, cfg.norm_eps, ma + D, ma, st));
+        else CK(launch_norm<T>(NORM_ADALN, x + off * D, D, xn + off * D, D, Ms, D, cfg.norm_eps, ma + D, ma, st));
       }
       if (D % 256 == 0) {
         // one launch: projection + q/k head RMSNorm + half-head RoPE + transposed V (gemm.hip fused QKV epilogue)
@@ -1161,22 +1207,26 @@ struct Engine : EngineBase {
         CKI(fp8_reserve(M, std::max(D, F)));
         CK(b_h8.reserve((size_t)(M + 256) * F));
         CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, b_q8.as<uint8_t>(), D, 1.0f / fp8_static[2 * l], gate_act));
-        GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
-        g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
-        g.A = b_q8.p; g.lda = D; g.W = q_wo[l]; g.ldw = D; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l]; g.w_scale = s_wo[l];
-        CKI(run(g, st));
       } else {
         CKI(attention(qkvg, 4 * D, qkvg + 3 * D, 4 * D, ao, D, rows, S, H, sg, 4, false, st, nullptr, 0, 0.f, gate_act));
-        GemmArgs g = G(ao, D, wo[l], D, x, D, M, D, D);
-        g.colscale = ma + 2 * D; g.res = x; g.ldres = D;
-        if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st, false, 2 * l));
+      }
+      for (const ModSeg& sgm : segs) {       // x += tanh(gate) * wo(attn): the gate is this segment's
+        const long off = (long)sgm.row0 * S;
+        const int Ms = sgm.nrows * S;
+        GemmArgs g = G(ao + off * D, D, wo[l], D, x + off * D, D, Ms, D, D);
+        g.colscale = sgm.mod + mao + 2 * D; g.res = x + off * D; g.ldres = D;
+        if (st8) {
+          g.A = b_q8.as<uint8_t>() + off * D; g.lda = D; g.W = q_wo[l]; g.ldw = D; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l]; g.w_scale = s_wo[l];
+        } else if (fp8) CKI(to_fp8(g, q_wo[l], s_wo[l], st, false, 2 * l));
         CKI(run(g, st));
       }
-      if (nq2) {
-        CKI(fp8_reserve(M, std::max(D, F)));
-        CK(launch_norm_adaln_fp8(x, D, b_q8.p, D, b_qs.as<float>(), M, D, cfg.norm_eps, mm + D, mm, st));
-      } else {
-        CK(launch_norm<T>(NORM_ADALN, x, D, xn, D, M, D, cfg.norm_eps, mm + D, mm, st));
+      if (nq2) CKI(fp8_reserve(M, std::max(D, F)));
+      for (const ModSeg& sgm : segs) {
+        const long off = (long)sgm.row0 * S;
+        const int Ms = sgm.nrows * S;
+        const T* mm = sgm.mod + mmo;
+        if (nq2) CK(launch_norm_adaln_fp8(x + off * D, D, b_q8.as<uint8_t>() + off * D, D, b_qs.as<float>() + off, Ms, D, cfg.norm_eps, mm + D, mm, st));
+        else CK(launch_norm<T>(NORM_ADALN, x + off * D, D, xn + off * D, D, Ms, D, cfg.norm_eps, mm + D, mm, st));
       }
       {
         GemmArgs g = G(xn, D, w13[l], D, hh, F, M, 2 * F, D);
@@ -1185,11 +1235,13 @@ struct Engine : EngineBase {
         if (st8 && g.fp8) { g.c8 = b_h8.p; g.c8_ld = F; g.c8_inv = 1.0f / fp8_static[2 * l + 1]; }
         CKI(run(g, st));
       }
-      {
-        GemmArgs g = G(hh, F, w2[l], F, x, D, M, D, F);
-        g.colscale = mm + 2 * D; g.res = x; g.ldres = D;
+      for (const ModSeg& sgm : segs) {       // x += tanh(gate) * w2(h)
+        const long off = (long)sgm.row0 * S;
+        const int Ms = sgm.nrows * S;
+        GemmArgs g = G(hh + off * F, F, w2[l], F, x + off * D, D, Ms, D, F);
+        g.colscale = sgm.mod + mmo + 2 * D; g.res = x + off * D; g.ldres = D;
         if (st8) {
-          g.A = b_h8.p; g.lda = F; g.W = q_w2[l]; g.ldw = F; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l + 1]; g.w_scale = s_w2[l];
+          g.A = b_h8.as<uint8_t>() + off * F; g.lda = F; g.W = q_w2[l]; g.ldw = F; g.fp8 = 1; g.a_scale = nullptr; g.a_scale_const = fp8_static[2 * l + 1]; g.w_scale = s_w2[l];
         } else if (fp8) CKI(to_fp8(g, q_w2[l], s_w2[l], st, false, 2 * l + 1));
         CKI(run(g, st));
       }
@@ -1240,20 +1292,31 @@ struct Engine : EngineBase {
     return ECHO_OK;
   }
 
-  int dit_forward(const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent, const int32_t* ton,
-                  const int32_t* son, float* v, hipStream_t st) override {
+  // temb: (n_t, E) timestep embeddings; row_t (host, rows) = which of them each row uses (nullptr: all rows use embedding 0)
+  int dit_forward(const void* x, const void* temb, int n_t, const int32_t* row_t, int rows, int B, int S, int start_pos, int use_latent,
+                  const int32_t* ton, const int32_t* son, float* v, hipStream_t st) override {
     if (!dit_ready) return fail("echo_finalize_dit was not called");
     if (rows < 1 || rows > MAXROWS || B < 1 || rows % B || B != kvB) return fail("bad rows/B");
     if (spk_T > 0 && (spkB < 1 || kvB % spkB)) return fail("the speaker cache's batch size must divide the text cache's");
+    if (n_t < 1 || n_t > rows || (n_t > 1 && !row_t)) return fail("bad timestep table (1 <= n_t <= rows, row_t needed when n_t > 1)");
     const int M = rows * S;
     CKI(reserve_dit_ws(M, rows, S));
-    CKI(compute_mod((const T*)temb, 1, st));
+    CKI(compute_mod((const T*)temb, n_t, st));
+    const long modstride = (long)2 * cfg.num_layers * 3 * cfg.model_size;
+    std::vector<ModSeg> segs;            // runs of consecutive rows with the same timestep
+    for (int r = 0; r < rows; ++r) {
+      const int ti = row_t ? row_t[r] : 0;
+      if (ti < 0 || ti >= n_t) return fail("row_t entry out of range");
+      const T* mod = b_mod.as<T>() + (long)ti * modstride;
+      if (!segs.empty() && segs.back().mod == mod) ++segs.back().nrows;
+      else segs.push_back(ModSeg{r, 1, mod});
+    }
     set_row_keys(rows, B, S, start_pos, use_latent != 0, ton, son);
     CKI(push_nkeys(st));
     // x (M, latent) -> xin (M, lat_pad) zero padded
     CK(hipMemcpy2DAsync(b_xin.p, lat_pad * sizeof(T), x, cfg.latent_size * sizeof(T), cfg.latent_size * sizeof(T), M,
                         hipMemcpyDeviceToDevice, st));
-    CKI(forward_rows(rows, B, S, start_pos, use_latent != 0, b_mod.as<T>(), st));
+    CKI(forward_rows(rows, B, S, start_pos, use_latent != 0, b_mod.as<T>(), st, &segs));
     CK(launch_convert_to_f32<T>(b_vout.as<T>(), 128, v, cfg.latent_size, M, cfg.latent_size, st));
     return ECHO_OK;
   }
@@ -1287,7 +1350,7 @@ struct Engine : EngineBase {
     e.x = xs; e.v = b_vout.p; e.ldv = 128; e.xin = b_xin.p; e.ld_xin = lat_pad;
     e.B = B; e.S = S; e.L = Lz; e.R = 1;
     e.R_next = p->steps[0].has_cfg ? 3 : 1;
-    e.init = 1; e.init_scale = p->init_scale;      // x_t = x_t * truncation_factor (inference.py:478-479); 1.0 = none, 0.0 is honoured
+    e.init = 1; e.init_scale = p->has_truncation ? p->init_scale : 1.0f;   // x_t = x_t * truncation_factor (inference.py:478-479) only when one was given; 0.0 is then honoured
     CK(launch_euler<T>(e, st));
     for (int i = 0; i < N; ++i) {
       const echo_step& sp = p->steps[i];
@@ -1465,24 +1528,7 @@ struct Engine : EngineBase {
     GemmArgs g = g_in;
     g.split3 = dac_split3 ? 1 : 0;
     CKI(plan_gemm<float>(g, st));
-    if (profiling) {
-      if (gemm_events_used == gemm_events.size()) {
-        hipEvent_t a, b;
-        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-        gemm_events.emplace_back(a, b);
-      }
-      if (gemm_event_flops.size() < gemm_events.size()) gemm_event_flops.resize(gemm_events.size(), 0.0);
-      gemm_event_flops[gemm_events_used] = 0.0;
-      if (gemm_event_shape.size() < gemm_events.size()) gemm_event_shape.resize(gemm_events.size());
-      gemm_event_shape[gemm_events_used] = {g.M, g.N, g.K, g.taps, g.swiglu, g.qkv_mode, g.fp8, g.cfg, g.ksplit, g.nbatch};
-      auto& e = gemm_events[gemm_events_used++];
-      CK(hipEventRecord(e.first, st));
-      CK(launch_gemm_nt<float>(g, st));
-      CK(hipEventRecord(e.second, st));
-      return ECHO_OK;
-    }
-    CK(launch_gemm_nt<float>(g, st));
-    return ECHO_OK;
+    return run_planned<float>(g, st, false);
   }
   static GemmArgs FG(const float* A, long lda, const float* W, long ldw, float* C, long ldc, long M, int N, int K) {
     GemmArgs g;
@@ -2083,7 +2129,11 @@ int echo_scale_speaker_kv(echo_ctx* ctx, float scale, int max_layers, void* stre
 }
 int echo_dit_forward(echo_ctx* ctx, const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
                      const int32_t* ton, const int32_t* son, float* v_out, void* stream) {
-  return ctx ? ctx->eng->dit_forward(x, temb, rows, B, S, start_pos, use_latent, ton, son, v_out, (hipStream_t)stream) : ECHO_ERR;
+  return ctx ? ctx->eng->dit_forward(x, temb, 1, nullptr, rows, B, S, start_pos, use_latent, ton, son, v_out, (hipStream_t)stream) : ECHO_ERR;
+}
+int echo_dit_forward_t(echo_ctx* ctx, const void* x, const void* temb, int n_t, const int32_t* row_t, int rows, int B, int S, int start_pos,
+                       int use_latent, const int32_t* ton, const int32_t* son, float* v_out, void* stream) {
+  return ctx ? ctx->eng->dit_forward(x, temb, n_t, row_t, rows, B, S, start_pos, use_latent, ton, son, v_out, (hipStream_t)stream) : ECHO_ERR;
 }
 int echo_sample_euler(echo_ctx* ctx, const echo_sampler_params* p, const float* x_init, float* latent_out, void* stream) {
   return ctx ? ctx->eng->sample_euler(p, x_init, latent_out, (hipStream_t)stream) : ECHO_ERR;
@@ -2114,6 +2164,11 @@ int echo_dac_hop(echo_ctx* ctx) {
   for (int i = 0; i < c.dac_n_rates; ++i) hop *= c.dac_rates[i];
   for (int i = 0; i < c.dac_n_up; ++i) hop *= c.dac_up_factors[i];
   return (int)hop;
+}
+int echo_debug_corrupt_tile(echo_ctx* ctx, int nth) {
+  if (!ctx || nth < 0) return ECHO_ERR;
+  ctx->eng->corrupt_countdown = nth;
+  return ECHO_OK;
 }
 int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out) {
   return ctx ? ctx->eng->debug_get_kv(which, layer, k_out, v_out, B_out, T_out) : ECHO_ERR;
@@ -2164,6 +2219,12 @@ static int op_status(hipError_t e) {
 
 int echo_op_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream) {
   return op_status(launch_quant_rows_fp8(x, ldx, q, ldq, scale, rows, K, (hipStream_t)stream));
+}
+
+int echo_op_norm_adaln_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int D, float eps,
+                           const void* scale1p, const void* shift, void* stream) {
+  if (D < 8 || (D & 7) || D > 4096 || rows < 1) return ECHO_ERR;
+  return op_status(launch_norm_adaln_fp8(x, ldx, q, ldq, scale, rows, D, eps, scale1p, shift, (hipStream_t)stream));
 }
 
 int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream) {

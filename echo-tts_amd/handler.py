@@ -216,7 +216,7 @@ class VoiceCache:
 @torch.inference_mode()
 def _sample_chunks_batched(model, fish_ae, pca_state, sample_fn, pieces: List[str], seed: int,
                            speaker_latent: Optional[torch.Tensor], speaker_mask: Optional[torch.Tensor], sequence_length: int,
-                           max_batch: int, speaker_kv=None) -> List[torch.Tensor]:
+                           max_batch: int, speaker_kv=None, indices: Optional[List[int]] = None) -> List[torch.Tensor]:
     """Up to `max_batch` chunks per sampler call.  Every row gets the noise the sequential path would draw for it (a (1, S, 80)
     draw from its own seed), text ids keep their 768 columns behind the key mask, the one voice is shared by all rows (encoded
     once with batch 1, or bound from the cache), decode stays per chunk; the flattening points of the whole batch come from one
@@ -229,13 +229,14 @@ def _sample_chunks_batched(model, fish_ae, pca_state, sample_fn, pieces: List[st
         speaker_latent = torch.zeros((1, 4, lz), device=device, dtype=dtype)
         speaker_mask = torch.zeros((1, 4), device=device, dtype=torch.bool)
     out: List[torch.Tensor] = []
+    idx = list(range(len(pieces))) if indices is None else list(indices)      # chunk numbers within the request: they set the seeds
     for g0 in range(0, len(pieces), max_batch):
         grp = pieces[g0:g0 + max_batch]
         B = len(grp)
         ids, tmask = get_text_input_ids_and_mask(grp, max_length=768, device=device)     # as sample_pipeline: 768 columns + key mask
         x0 = torch.cat([torch.randn((1, sequence_length, lz), device=device, dtype=torch.float32,
-                                    generator=torch.Generator(device=device).manual_seed(seed + (g0 + i) * 1000)) for i in range(B)], 0)
-        lat = sample_fn(model, speaker_latent, speaker_mask, ids, tmask, seed + g0 * 1000, x_init=x0, speaker_kv=speaker_kv)
+                                    generator=torch.Generator(device=device).manual_seed(seed + idx[g0 + i] * 1000)) for i in range(B)], 0)
+        lat = sample_fn(model, speaker_latent, speaker_mask, ids, tmask, seed + idx[g0] * 1000, x_init=x0, speaker_kv=speaker_kv)
         cut = find_flattening_points(lat)
         for i in range(B):
             audio = ae_decode(fish_ae, pca_state, lat[i:i + 1])
@@ -264,7 +265,23 @@ def _run_job(job_input: Dict, model, fish_ae, pca_state, speaker_latent, speaker
     seq = parameters.get("sequence_length", SAMPLER_DEFAULTS["sequence_length"])
     seq = 640 if seq is None else int(seq)
     max_batch = int(parameters.get("max_chunk_batch", 8))
-    if max_batch > 1 and len(pieces) > 1:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and len(pieces) > 1 and parameters.get("data_parallel", True):
+        # the chunks of a request are independent units with their own seeds (handler.py:747-759).  Every rank of the job
+        # calls the handler with the SAME request; chunk i goes to rank i % world (parallel.shard_units), each rank runs its share as
+        # rows of one sampler call, and rank 0 receives the waveforms in chunk order and assembles them.  The other ranks return
+        # (None, seed, n): they did their part.  No collective inside the sampler.
+        from . import parallel as P
+
+        def work_many(units: List[int]) -> Dict[int, torch.Tensor]:
+            wav = _sample_chunks_batched(model, fish_ae, pca_state, sample_fn, [pieces[u] for u in units], seed, speaker_latent, speaker_mask,
+                                         seq, max(1, max_batch), speaker_kv=speaker_kv, indices=units)
+            return {u: w_.reshape(-1) for u, w_ in zip(units, wav)}
+        gathered = P.run_data_parallel_batched(len(pieces), work_many)
+        if gathered is None:
+            return None, seed, len(pieces)
+        chunks = [w_.to(model.device).reshape(1, -1) for w_ in gathered]
+    elif max_batch > 1 and len(pieces) > 1:
         chunks = _sample_chunks_batched(model, fish_ae, pca_state, sample_fn, pieces, seed, speaker_latent, speaker_mask, seq, max_batch,
                                         speaker_kv=speaker_kv)
     else:
@@ -284,6 +301,11 @@ def _run_job(job_input: Dict, model, fish_ae, pca_state, speaker_latent, speaker
     if audio.dim() == 1:
         audio = audio.unsqueeze(0)
     return audio, seed, len(pieces)
+
+
+def _is_worker_rank() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() != 0
 
 
 def _validate_text(job_input: Dict) -> Optional[Dict]:
@@ -313,6 +335,8 @@ def synthesize(job_input: Dict, model, fish_ae, pca_state, speaker_latent: Optio
             speaker_latent, speaker_mask = get_speaker_latent_and_mask(fish_ae, pca_state, speaker_audio.to(model.device))
             speaker_latent = speaker_latent.to(model.dtype)
         audio, seed, n = _run_job(job_input, model, fish_ae, pca_state, speaker_latent, speaker_mask)
+        if audio is None:                  # a worker rank of a data-parallel job: rank 0 holds the assembled audio
+            return {"status": "worker", "chunks": n, "seed": seed}
         return {"audio": audio, "sample_rate": SAMPLE_RATE, "duration": audio.shape[-1] / SAMPLE_RATE, "chunks": n,
                 "seed": seed, "text_length": len(job_input.get("text"))}
     except Exception as e:  # same contract as handler.py:797-803
@@ -390,6 +414,8 @@ def _synthesize(job_input: Dict, job_id: Optional[str] = None) -> Dict:
             if speaker_kv is None:
                 return {"error": f"speaker_voice '{speaker_voice_name}' not found"}
         audio_out, seed, n_chunks = _run_job(job_input, model, fish_ae, pca_state, None, None, speaker_kv=speaker_kv)
+        if audio_out is None and _is_worker_rank():
+            return {"status": "worker", "metadata": {"seed": seed, "device": str(model.device), "chunks": n_chunks}}
         if audio_out is None or len(audio_out) == 0:
             return {"error": "No audio generated"}
         duration_seconds = len(audio_out[0]) / 44_100

@@ -255,6 +255,7 @@ def run_euler(model: EchoDiT, x_init: torch.Tensor, steps, temb: torch.Tensor, c
     p.B, p.S, p.num_steps = B, S, len(steps)
     p.start_pos, p.use_latent = int(start_pos), int(use_latent)
     p.cfg_scale_text, p.cfg_scale_speaker = float(cfg_scale_text), float(cfg_scale_speaker)
+    p.has_truncation = int(truncation_factor is not None)        # inference.py:478 `if truncation_factor is not None`
     p.init_scale = 1.0 if truncation_factor is None else float(truncation_factor)
     p.kv_scale = 1.0 if speaker_kv_scale is None else float(speaker_kv_scale)
     p.kv_max_layers = -1 if speaker_kv_max_layers is None else int(speaker_kv_max_layers)

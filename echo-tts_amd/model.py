@@ -313,17 +313,28 @@ class EchoDiT:
         B = self._kvB
         if rows % B:
             raise ValueError("batch rows must be a multiple of the KV batch")
-        tt = t.to("cpu")
-        if not bool((tt == tt[0]).all()):
-            raise NotImplementedError("all rows of one forward must share the timestep (the sampler always does)")
-        temb = timestep_embedding(tt[:1].to(self._dtype), self.config.timestep_embed_size).to(self._device).contiguous()
+        # t (rows,) - any values (model.py:563-604): the distinct timesteps get one modulation table each, row_t maps rows to them
+        tt = t.detach().to("cpu").reshape(-1)
+        if tt.numel() == 1:
+            tt = tt.expand(rows)
+        if tt.numel() != rows:
+            raise ValueError(f"t must have one entry per row ({rows}), got {tt.numel()}")
+        tt = tt.to(self._dtype)                              # the model sees t in its own dtype (inference.py:489, model.py:40)
+        uniq: List[float] = []
+        row_t: List[int] = []
+        for v in tt.float().tolist():
+            if v not in uniq:
+                uniq.append(v)
+            row_t.append(uniq.index(v))
+        temb = timestep_embedding(torch.tensor(uniq, dtype=torch.float32).to(self._dtype), self.config.timestep_embed_size)
+        temb = temb.to(self._device).contiguous()
         ton = self._row_switch(text_mask, kv_cache_text.mask, rows, B, 1)
         son = self._row_switch(speaker_mask, kv_cache_speaker.mask, rows, kv_cache_speaker.batch, self.config.speaker_patch_size)
         xin = x.to(self._device, self._dtype).contiguous()
         out = torch.empty((rows, S, Lz), dtype=torch.float32, device=self._device)
-        L.check(self._lib.echo_dit_forward(self._ctx, xin.data_ptr(), temb.data_ptr(), rows, B, S, int(start_pos or 0),
-                                           int(kv_cache_latent is not None), (C.c_int32 * rows)(*ton), (C.c_int32 * rows)(*son),
-                                           out.data_ptr(), self._stream()), self._ctx)
+        L.check(self._lib.echo_dit_forward_t(self._ctx, xin.data_ptr(), temb.data_ptr(), len(uniq), (C.c_int32 * rows)(*row_t), rows, B, S,
+                                             int(start_pos or 0), int(kv_cache_latent is not None), (C.c_int32 * rows)(*ton),
+                                             (C.c_int32 * rows)(*son), out.data_ptr(), self._stream()), self._ctx)
         return out
 
     __call__ = forward

@@ -25,7 +25,7 @@ extern "C" {
 
 #define ECHO_F32 0
 #define ECHO_BF16 1
-#define ECHO_ABI_VERSION 6
+#define ECHO_ABI_VERSION 7
 
 typedef struct echo_ctx echo_ctx;
 
@@ -127,6 +127,12 @@ int echo_reserve_workspace(echo_ctx* ctx, int B, int S, int Tt, int Ts, int T_da
 int echo_dit_forward(echo_ctx* ctx, const void* x, const void* temb, int rows, int B, int S, int start_pos, int use_latent,
                      const int32_t* row_text_on, const int32_t* row_spk_on, float* v_out, void* stream);
 
+/* ABI 7: the same forward with PER-ROW timesteps (model.py:563-604 takes any t (R,); model.py:27-43): temb (n_t, timestep_embed) of T
+ * holds the embeddings of the n_t distinct timesteps, row_t (host, rows) names the one each row uses.  Rows are processed together;
+ * only the launches that read the AdaLN modulation run once per run of consecutive rows with equal row_t. */
+int echo_dit_forward_t(echo_ctx* ctx, const void* x, const void* temb, int n_t, const int32_t* row_t, int rows, int B, int S, int start_pos,
+                       int use_latent, const int32_t* row_text_on, const int32_t* row_spk_on, float* v_out, void* stream);
+
 typedef struct {
   int has_cfg;                   /* inference.py:484 */
   float dt;                      /* fp32 (t_next - t), inference.py:515 */
@@ -139,7 +145,9 @@ typedef struct {
   int B, S, num_steps;
   int start_pos, use_latent;     /* blockwise: inference_blockwise.py:91-94 */
   float cfg_scale_text, cfg_scale_speaker;
-  float init_scale;              /* truncation_factor (inference.py:478-479: x_t = x_t * factor; 0.0 is honoured), 1 when None */
+  int has_truncation;            /* ABI 7: 0 = truncation_factor is None (init_scale ignored: a zero-initialised struct samples from the
+                                  * un-truncated noise); 1 = x_t = x_t * init_scale (inference.py:478-479), a literal 0.0 included */
+  float init_scale;              /* truncation_factor; read only when has_truncation != 0 */
   float kv_scale; int kv_max_layers;   /* used by kv_unscale_after steps: multiply by 1/kv_scale */
   const echo_step* steps;        /* host, num_steps entries */
   const void* temb;              /* device, (num_steps, timestep_embed) of T */
@@ -216,6 +224,11 @@ int echo_op_gemm(int dtype, const echo_gemm_desc* d, void* stream);
 int echo_op_presplit_weights(float* w, int64_t rows, int64_t ld, void* stream);
 /* bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (amax / 448): the operand format of the fp8 GEMM */
 int echo_op_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream);
+/* ABI 7: the fp8 engine's AdaLN-apply (model.py:76-83 on bf16 rows: x_hat * scale1p + shift, rounded to bf16) whose output leaves as
+ * e4m3 bytes + one fp32 scale per row (amax / 448) - echo_op_norm(mode 0) followed by echo_op_quant_rows_fp8 in one pass.
+ * D % 8 == 0, D <= 4096. */
+int echo_op_norm_adaln_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int D, float eps,
+                           const void* scale1p, const void* shift, void* stream);
 int echo_op_pack_rows(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int rows,
                       int cols, int dst_row0, int swiglu_half, void* stream);
 
@@ -264,6 +277,12 @@ int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_h
 /* test hook: copy one DiT layer's cached K and V (which: 0 text, 1 speaker, 2 latent) as fp32 (B, T, model_size);
  * K is post-k_norm(/RoPE), V as projected.  Synchronous.  *B_out / *T_out receive the cache geometry. */
 int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out);
+
+/* ABI 7, test instrument ("does the parity test have teeth?"): the nth plain-store launch of the ping-pong GEMM kernel (a wo or w2
+ * linear of an EchoDiT block) from now on has its output tile (rows 256..511, columns 256..511) negated right after the launch - what
+ * one wrong entry in the kernel's tile walk would produce.  nth = 0 disarms.  tests/test_gpu_engine.py shows that its full-depth
+ * budgets reject such a forward. */
+int echo_debug_corrupt_tile(echo_ctx* ctx, int nth);
 
 /* timing of the engine's phases, filled by the last echo_sample_euler / echo_dac_decode when
  * echo_set_profiling(ctx, 1) was called (HIP events on the caller's stream; adds synchronisation) */

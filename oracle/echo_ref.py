@@ -151,6 +151,10 @@ def lowrank_adaln(w: Weights, p: str, x: Tensor, cond: Tensor, eps: float) -> Tu
         return F.linear(h, w[f"{p}.{name}_up.weight"], w[f"{p}.{name}_up.bias"]) + c
 
     shift, scale, gate = refine("shift", shift), refine("scale", scale), refine("gate", gate)
+    if _LINEAR_TAPS is not None:
+        _LINEAR_TAPS[f"{p}.in"] = x.clone()
+        _LINEAR_TAPS[f"{p}.scale1p"] = (scale + 1).clone()
+        _LINEAR_TAPS[f"{p}.shift"] = shift.clone()
     dt = x.dtype
     x = x.float()
     x = x * torch.rsqrt(torch.pow(x.float(), 2).mean(dim=-1, keepdim=True) + eps)
@@ -184,18 +188,33 @@ def fake_quant_static_e4m3(x: Tensor, s: float) -> Tensor:
     return (x.float() / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * s
 
 
+# Teacher-forcing taps (tests only): when a dict is installed, every block linear records its input and output under
+# "<block prefix>.<linear>.in" / ".out", so that a test can feed exactly these operands through the engine's single kernels.
+_LINEAR_TAPS: Optional[Dict[str, Tensor]] = None
+
+
+def set_linear_taps(taps: Optional[Dict[str, Tensor]]) -> None:
+    global _LINEAR_TAPS
+    _LINEAR_TAPS = taps
+
+
 def block_linear(x: Tensor, wt: Tensor, p: str, name: str = "") -> Tensor:
     """nn.Linear of an EchoDiT block (attention wq / wk / wv / gate / wo, mlp w1 / w3 / w2); fp8 operands when C5 mode is on."""
     if _FP8_BLOCK_LINEARS and p.startswith("blocks."):
         st = _FP8_ACT_STATIC.get(f"{p}.{name}") if (_FP8_ACT_STATIC and name) else None
         xq = fake_quant_static_e4m3(x, st) if st is not None else fake_quant_rows_e4m3(x)
-        return (xq @ fake_quant_rows_e4m3(wt).t()).to(x.dtype)
-    return F.linear(x, wt)
+        y = (xq @ fake_quant_rows_e4m3(wt).t()).to(x.dtype)
+    else:
+        y = F.linear(x, wt)
+    if _LINEAR_TAPS is not None and name:
+        _LINEAR_TAPS[f"{p}.{name}.in"] = x.clone()
+        _LINEAR_TAPS[f"{p}.{name}.out"] = y.clone()
+    return y
 
 
 def swiglu(w: Weights, p: str, x: Tensor) -> Tensor:
     """w2(silu(w1 x) * w3 x).  model.py:307-308."""
-    return block_linear(F.silu(block_linear(x, w[f"{p}.w1.weight"], p)) * block_linear(x, w[f"{p}.w3.weight"], p), w[f"{p}.w2.weight"], p, "w2")
+    return block_linear(F.silu(block_linear(x, w[f"{p}.w1.weight"], p, "w1")) * block_linear(x, w[f"{p}.w3.weight"], p, "w3"), w[f"{p}.w2.weight"], p, "w2")
 
 
 def encoder_self_attention(w: Weights, p: str, x: Tensor, mask: Optional[Tensor], fc: Tensor,
@@ -294,12 +313,12 @@ def joint_attention(w: Weights, cfg: DiTConfig, p: str, x: Tensor, text_mask: Te
     """JointAttention.forward: keys = [self | latent | text | speaker].  model.py:204-268."""
     b, s = x.shape[:2]
     h = cfg.num_heads
-    q = block_linear(x, w[f"{p}.wq.weight"], p).reshape(b, s, h, -1)
-    k = block_linear(x, w[f"{p}.wk.weight"], p).reshape(b, s, h, -1)
-    v = block_linear(x, w[f"{p}.wv.weight"], p).reshape(b, s, h, -1)
+    q = block_linear(x, w[f"{p}.wq.weight"], p, "wq").reshape(b, s, h, -1)
+    k = block_linear(x, w[f"{p}.wk.weight"], p, "wk").reshape(b, s, h, -1)
+    v = block_linear(x, w[f"{p}.wv.weight"], p, "wv").reshape(b, s, h, -1)
     q = rms_norm(q, w[f"{p}.q_norm.weight"], cfg.norm_eps)
     k = rms_norm(k, w[f"{p}.k_norm.weight"], cfg.norm_eps)
-    g = block_linear(x, w[f"{p}.gate.weight"], p)
+    g = block_linear(x, w[f"{p}.gate.weight"], p, "gate")
     fq = fc[start_pos:start_pos + s]
     q = rotate_first_half_of_heads(q, fq)
     k = rotate_first_half_of_heads(k, fq)
@@ -386,12 +405,21 @@ def sample_euler(w: Weights, cfg: DiTConfig, dtype: torch.dtype, speaker_latent:
                  rescale_k: Optional[float], rescale_sigma: Optional[float], speaker_kv_scale: Optional[float],
                  speaker_kv_max_layers: Optional[int], speaker_kv_min_t: Optional[float],
                  sequence_length: Optional[int] = None, x_init: Optional[Tensor] = None,
-                 trace: Optional[List[Tensor]] = None) -> Tensor:
+                 trace: Optional[List[Tensor]] = None, model_t_dtype: Optional[torch.dtype] = None) -> Tensor:
     """sample_euler_cfg_independent_guidances.  inference.py:427-517.
 
     ``x_init`` (already multiplied by nothing) overrides the RNG draw so that device-specific
     generators do not enter parity tests; truncation is still applied to it.
+
+    ``model_t_dtype`` (tests only; None = the reference): the timestep handed to the MODEL is first rounded to that dtype, everything
+    else stays as it is.  The reference's bf16 path rounds t to bf16 before the timestep embedding (inference.py:488-489,
+    model.py:40: bf16(0.666) moves embedding phases by up to 2 rad), which alone puts its bf16 run ~1 RMS from its fp32 run;
+    an fp32 run at the bf16-ROUNDED timesteps is the reference a bf16 implementation's own rounding noise can be measured against.
     """
+    def model_t(n: int, t: Tensor) -> Tensor:
+        tt = torch.ones((n,), device=dev) * t
+        return (tt.to(model_t_dtype).to(dtype) if model_t_dtype is not None else tt.to(dtype))
+
     if sequence_length is None:
         sequence_length = 640
     dev = text_input_ids.device
@@ -415,11 +443,11 @@ def sample_euler(w: Weights, cfg: DiTConfig, dtype: torch.dtype, speaker_latent:
         t, tn = ts[i], ts[i + 1]
         if ((t >= cfg_min_t) * (t <= cfg_max_t)).item():
             vc, vut, vus = dit_forward(
-                w, cfg, torch.cat([x, x, x], dim=0).to(dtype), (torch.ones((b * 3,), device=dev) * t).to(dtype),
+                w, cfg, torch.cat([x, x, x], dim=0).to(dtype), model_t(b * 3, t),
                 tm3, sm3, kv_t3, kv_s3).float().chunk(3, dim=0)
             v = vc + cfg_scale_text * (vc - vut) + cfg_scale_speaker * (vc - vus)
         else:
-            v = dit_forward(w, cfg, x.to(dtype), (torch.ones((b,), device=dev) * t).to(dtype),
+            v = dit_forward(w, cfg, x.to(dtype), model_t(b, t),
                             text_mask, speaker_mask, kv_t, kv_s).float()
         if rescale_k is not None and rescale_sigma is not None:
             v = temporal_score_rescale(v, x, t, rescale_k, rescale_sigma)
@@ -877,6 +905,21 @@ def make_dit_weights(cfg: DiTConfig, seed: int = 0, with_blockwise: bool = True)
     mat("out_proj.weight", cfg.latent_size, d)
     mat("out_proj.bias", cfg.latent_size)
     return w
+
+
+def stabilise_dit_weights(w: Weights, cfg: DiTConfig) -> Weights:
+    """A second, WELL-CONDITIONED recipe for full-depth tests: every residual branch of the EchoDiT blocks (attention wo, mlp w2) and
+    every low-rank AdaLN refinement (`*_up` weight and bias) is scaled by 1 / sqrt(2 * num_layers), bf16-representable like the rest.
+    With N(0, 0.02) everywhere, 24 random layers under CFG scale 8 amplify each bf16 rounding until PyTorch's own bf16 run is ~1 RMS
+    away from its fp32 run - a budget that rejects nothing.  With this recipe the residual stream keeps its scale through the depth
+    (the usual 1/sqrt(2L) output-projection initialisation) and bf16-vs-fp32 stays at the 1e-2 level, so a budget of 1.5 x that has
+    teeth: one wrong 256 x 256 output tile in one GEMM launch of a 24-layer forward exceeds it."""
+    f = 1.0 / math.sqrt(2.0 * cfg.num_layers)
+    out = dict(w)
+    for k, v in w.items():
+        if k.startswith("blocks.") and (k.endswith(".attention.wo.weight") or k.endswith(".mlp.w2.weight") or "_up." in k):
+            out[k] = (v.float() * f).bfloat16().to(v.dtype)
+    return out
 
 
 def make_dac_weights(cfg: DacConfig, seed: int = 0) -> Weights:

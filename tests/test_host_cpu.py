@@ -29,7 +29,7 @@ def test_struct_sizes_match_the_header():
     # sizes computed from the C declarations (ints / floats / pointers / int64), guarding field drift
     assert ctypes.sizeof(L.EchoStep) == 7 * 4
     assert ctypes.sizeof(L.EchoConfig) == 4 * (1 + 5 + 1 + 5 + 5 + 2 + 1 + 3 + 8 + 5 + 1 + 4 + 1 + (2 + 8 + 8 + 1) + 4 + 1)   # ... + dit_fp8
-    assert ctypes.sizeof(L.EchoSamplerParams) == 10 * 4 + 2 * 8
+    assert ctypes.sizeof(L.EchoSamplerParams) == 11 * 4 + 4 + 2 * 8      # 11 ints / floats (ABI 7: + has_truncation), padding to 8, 2 pointers
 
 
 def test_product_fails_loudly_without_gpu():
@@ -188,3 +188,36 @@ def test_fp8_static_scale_helpers(tmp_path):
         R.set_fp8_block_linears(False)
     assert not torch.equal(a, b) and torch.equal(b, c)
     assert torch.equal(R.block_linear(x, w, "blocks.0.mlp", "w2"), torch.nn.functional.linear(x, w))   # switched off again
+
+
+def test_bench_host_logic(golden, monkeypatch):
+    """bench.py without a GPU: C3's preset lengths are the reference tokenizer's (tests/golden/meta.json), and `--gpus N` outside a
+    torchrun environment spawns the ranks BEFORE any GPU call (torch.cuda is never asked) and relays the child job's exit code."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.PRESET_TOKEN_LENGTHS == golden["__meta__"]["host"]["preset_token_lengths"]
+    seen = {}
+
+    class FakePopen:
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["env"] = cmd, kw.get("env", {})
+            self.stdout = iter(["noise\n", '{"metric": "m", "value": 1.0}\n'])
+
+        def wait(self):
+            return 0
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the spawning parent touched the GPU")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    ids, tmask, x0 = None, None, None
+    assert bench.dit_gemm_flops(1) > 1.3e14 and bench.free_port() > 0

@@ -17,6 +17,31 @@ def _free_port() -> int:
     return port
 
 
+LONG_TEXT = " ".join(f"Sentence number {i} of a long request, which the handler cuts into chunks." for i in range(12))
+
+
+def _fake_chunks(model, fish_ae, pca_state, sample_fn, pieces, seed, speaker_latent, speaker_mask, sequence_length, max_batch,
+                 speaker_kv=None, indices=None):
+    """Stands in for the GPU sampler + decode: chunk i of a request -> a waveform that encodes (seed, i, its text length)."""
+    idx = list(range(len(pieces))) if indices is None else list(indices)
+    return [torch.full((1, 100 + 7 * i), float(seed + 1000 * i + len(p_) % 13)) for i, p_ in zip(idx, pieces)]
+
+
+def _handler_job(rank: int):
+    """Runs the same request through handler._run_job on this rank; returns True when this rank got the full, correct audio."""
+    import types
+    from echo_tts_amd import handler as H
+    H._sample_chunks_batched = _fake_chunks
+    model = types.SimpleNamespace(device=torch.device("cpu"), dtype=torch.float32, config=types.SimpleNamespace(latent_size=80))
+    job = {"text": LONG_TEXT, "parameters": {"seed": 5, "max_chars_per_chunk": 120, "normalize_boundaries": False, "enable_crossfade": False}}
+    audio, seed, n = H._run_job(job, model, None, None, None, None)
+    pieces = H.chunk_text_for_audio(LONG_TEXT, max_chars=120, target_duration_seconds=10.0)
+    want = torch.cat(_fake_chunks(None, None, None, None, pieces, 5, None, None, 640, 8), dim=-1)
+    if audio is None:
+        return False
+    return n == len(pieces) and n > 3 and seed == 5 and torch.equal(audio, want)
+
+
 def _worker(rank: int, world: int, port: int, q) -> None:
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r, w, _ = P.init_distributed(backend="gloo")
@@ -38,6 +63,20 @@ def _worker(rank: int, world: int, port: int, q) -> None:
         ok = ok and [t.tolist() for t in res] == [[float(i)] * (i + 1) for i in range(5)]
     else:
         ok = ok and res is None
+    # the batched runner: each rank's share through ONE call, ragged 2-D results, uneven unit count (5 units on 2 ranks)
+    calls = []
+
+    def many(units):
+        calls.append(list(units))
+        return {u: torch.arange(3 * (u + 2), dtype=torch.float32).reshape(3, u + 2) + u for u in units}
+    res = P.run_data_parallel_batched(5, many)
+    ok = ok and calls == [P.shard_units(5, r, w)]
+    if r == 0:
+        ok = ok and all(torch.equal(res[u], torch.arange(3 * (u + 2), dtype=torch.float32).reshape(3, u + 2) + u) for u in range(5))
+    else:
+        ok = ok and res is None
+    # the handler's data-parallel path: every rank gets the same request, rank 0 the assembled audio in chunk order
+    ok = ok and _handler_job(r) == (r == 0)
     q.put((r, ok, P.shard_units(5, r, w)))
     dist.barrier()
     dist.destroy_process_group()
