@@ -391,7 +391,9 @@ struct Engine : EngineBase {
             !g.snake_alpha && !g.C2 && g.act != 2 && g.store_main && (!g.qkv_mode || g.qkv_D % 256 == 0) && (!g.res || (g.ldres & 7) == 0) &&
             (g.vec_mod & 7) == 0) best.cfg = 5;
         else if (big && !g.qkv_mode) best.cfg = g.N % 192 == 0 && g.N % 256 != 0 ? 8 : g.N % 96 == 0 && g.N % 128 != 0 ? 9 : 2;
-        else if (g.nbatch == 1 && !g.qkv_mode && t128 <= 128) {
+        else if (sizeof(U) == 2 && g.nbatch == 1 && !g.qkv_mode && t128 <= 128) {
+          // bf16 engine only: the fp32 parity engine keeps one summation chain per output for every unlisted shape, so that e.g. a voice
+          // encoded with batch 1 (in_proj: nbatch 1) and the same voice replicated over a batch (nbatch B) agree bit for bit
           static const int kKs[] = {8, 6, 4, 3, 2};
           for (int ks : kKs)
             if (t128 * ks <= 256 && nk / ks >= 4) { best.ksplit = ks; break; }
@@ -494,7 +496,7 @@ struct Engine : EngineBase {
       return ECHO_OK;
     }
     CK(launch_planned<U>(g, st));
-    if (corrupt_countdown > 0 && g.cfg == 5 && !g.qkv_mode && !g.swiglu && !g.c8 && g.nbatch == 1 && g.M >= 512 && g.N >= 512 && --corrupt_countdown == 0)
+    if (corrupt_countdown > 0 && !g.qkv_mode && !g.swiglu && !g.c8 && g.nbatch == 1 && g.store_main && g.M >= 512 && g.N >= 512 && --corrupt_countdown == 0)
       hipLaunchKernelGGL(negate_tile_kernel<U>, dim3(256), dim3(256), 0, st, (U*)g.C, g.ldc, 256, 256, 256, 256);
     return ECHO_OK;
   }

@@ -278,10 +278,10 @@ int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_h
  * K is post-k_norm(/RoPE), V as projected.  Synchronous.  *B_out / *T_out receive the cache geometry. */
 int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out);
 
-/* ABI 7, test instrument ("does the parity test have teeth?"): the nth plain-store launch of the ping-pong GEMM kernel (a wo or w2
- * linear of an EchoDiT block) from now on has its output tile (rows 256..511, columns 256..511) negated right after the launch - what
- * one wrong entry in the kernel's tile walk would produce.  nth = 0 disarms.  tests/test_gpu_engine.py shows that its full-depth
- * budgets reject such a forward. */
+/* ABI 7, test instrument ("does the parity test have teeth?"): the nth plain-store GEMM launch with M >= 512 and N >= 512 from now on
+ * (in an EchoDiT forward: in_proj, then wo and w2 of every block, whatever tile kernel runs them) has its output tile (rows 256..511,
+ * columns 256..511) negated right after the launch - what one wrong entry in a kernel's tile walk would produce.  nth = 0 disarms.
+ * tests/test_gpu_engine.py shows that its full-depth checks reject such a forward. */
 int echo_debug_corrupt_tile(echo_ctx* ctx, int nth);
 
 /* timing of the engine's phases, filled by the last echo_sample_euler / echo_dac_decode when
