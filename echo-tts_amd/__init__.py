@@ -14,3 +14,4 @@ from .inference import (  # noqa: F401
     sample_pipeline_chunked, tokenizer_encode,
 )
 from .inference_blockwise import sample_blockwise, sample_blockwise_euler_cfg_independent_guidances  # noqa: F401
+from .audio_io import load_audio, read_wav, resample, wav_bytes  # noqa: F401

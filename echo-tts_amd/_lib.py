@@ -136,6 +136,7 @@ SIGNATURES = {
     "echo_op_transpose_heads": (C.c_int, [C.c_int, vp, c_i64, vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "echo_debug_get_kv": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "echo_debug_corrupt_tile": (C.c_int, [vp, C.c_int]),
+    "echo_op_resample": (C.c_int, [vp, c_i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
     "echo_voice_capture": (C.c_int, [vp, C.POINTER(vp), vp]),
     "echo_voice_bind": (C.c_int, [vp, vp, vp]),
     "echo_voice_bytes": (c_i64, [vp]),

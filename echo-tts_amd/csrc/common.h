@@ -247,6 +247,9 @@ hipError_t launch_trailing_quiet(const float* const* chunks, const long* lens, i
 hipError_t launch_assemble_chunks(const float* const* src, const long* start, const long* len, const long* valid, const int* ov, int n,
                                   float* out, long total, hipStream_t st);
 
+// out[f * up + p] = sum_k bank[p][k] * x[f * down + k - width] (zero outside [0, n)): polyphase sinc resampling, bank (up, taps) built by the host
+hipError_t launch_resample(const float* x, long n, const float* bank, int taps, int up, int down, int width, float* out, long n_out, hipStream_t st);
+
 // ---------------------------------------------------------------- DAC helpers (dac.hip)
 // All take channels-last fp32 activations x[t][c]; S = time steps per batch item (causal padding restarts there).
 hipError_t launch_ae_rope(float* x, long ldx, int rows, int S, int H, int HD, const float* cache /*(pos,HD/2,2)*/, hipStream_t st);

@@ -2326,4 +2326,9 @@ int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_h
   return op_status(launch_assemble_chunks(src_host, st_, ln_, va_, ov_, n, out_dev, (long)total, (hipStream_t)stream));
 }
 
+int echo_op_resample(const float* x_dev, int64_t n, const float* bank_dev, int taps, int up, int down, int width, float* out_dev, int64_t n_out,
+                     void* stream) {
+  return op_status(launch_resample(x_dev, (long)n, bank_dev, taps, up, down, width, out_dev, (long)n_out, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -115,6 +115,31 @@ hipError_t launch_trailing_quiet(const float* const* chunks, const long* lens, i
   return hipGetLastError();
 }
 
+// ---- polyphase FIR resampling (inference.py:104-113 load_audio -> torchaudio.functional.resample, the sinc / Hann-window kernel bank is built by
+// the host): out[f * up + p] = sum_k bank[p][k] * x[f * down + k - width], x read as zero outside [0, n).  One thread per output sample;
+// a wave reads 64 * down / up consecutive inputs plus the filter span from L2: HBM-bound on at most a few MB.
+__global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ x, long n, const float* __restrict__ bank, int taps, int up, int down,
+                                                       int width, float* __restrict__ out, long n_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const long f = i / up;
+  const int p = (int)(i - f * up);
+  const float* b = bank + (long)p * taps;
+  const long x0 = f * down - width;
+  float acc = 0.f;
+  for (int k = 0; k < taps; ++k) {
+    const long j = x0 + k;
+    if (j >= 0 && j < n) acc = __fmaf_rn(b[k], x[j], acc);
+  }
+  out[i] = acc;
+}
+
+hipError_t launch_resample(const float* x, long n, const float* bank, int taps, int up, int down, int width, float* out, long n_out, hipStream_t st) {
+  if (!x || !bank || !out || n < 1 || n_out < 1 || taps < 1 || up < 1 || down < 1 || width < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, x, n, bank, taps, up, down, width, out, n_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_assemble_chunks(const float* const* src, const long* start, const long* len, const long* valid, const int* ov, int n,
                                   float* out, long total, hipStream_t st) {
   if (n < 1 || n > ECHO_MAX_CHUNKS || total < 0) return hipErrorInvalidValue;

@@ -101,6 +101,10 @@ def get_text_input_ids_and_mask(text_arr: List[str], max_length: Optional[int], 
     return ids, mask
 
 
+# --------------------------------------------------------------------------- audio input (reference inference.py:104-113)
+from .audio_io import load_audio  # noqa: E402,F401  (same name and arguments as the reference)
+
+
 # --------------------------------------------------------------------------- autoencoder glue
 @dataclass
 class PCAState:

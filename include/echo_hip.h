@@ -274,6 +274,13 @@ int echo_op_trailing_quiet(const float* const* chunks_host, const int64_t* lens_
 int echo_op_assemble_chunks(const float* const* src_host, const int64_t* start_host, const int64_t* len_host, const int64_t* valid_host,
                             const int32_t* overlap_host, int n, float* out_dev, int64_t total, void* stream);
 
+/* ABI 7, SURVEY.md 8f-4 `load_audio` (inference.py:104-113: torchaudio.functional.resample to 44.1 kHz): polyphase FIR resampling of one mono
+ * signal on the device.  bank (up, taps) fp32 = the windowed-sinc filters of the `up` output phases (built by the host:
+ * echo_tts_amd.inference.sinc_resample_bank restates torchaudio's published sinc_interp_hann kernel); out[f * up + p] =
+ * sum_k bank[p][k] * x[f * down + k - width], x = 0 outside [0, n).  The caller crops to ceil(up * n / down) samples. */
+int echo_op_resample(const float* x_dev, int64_t n, const float* bank_dev, int taps, int up, int down, int width, float* out_dev, int64_t n_out,
+                     void* stream);
+
 /* test hook: copy one DiT layer's cached K and V (which: 0 text, 1 speaker, 2 latent) as fp32 (B, T, model_size);
  * K is post-k_norm(/RoPE), V as projected.  Synchronous.  *B_out / *T_out receive the cache geometry. */
 int echo_debug_get_kv(echo_ctx* ctx, int which, int layer, float* k_out, float* v_out, int* B_out, int* T_out);

@@ -1277,3 +1277,40 @@ def test_c4_blockwise_at_its_stated_size_with_crossfade(golden):
     ref = H.crossfade_chunks(wav_want, 4410)
     assert out.shape == ref.shape and out.shape[-1] == 2 * 640 * 2048 - 4410
     assert rms(out, ref) < WAV_TOL
+
+
+def test_load_audio_resampler_on_the_device(tmp_path):
+    """SURVEY 8f-4 `load_audio` (reference inference.py:104-113).  PARITY UNPINNED by the reference: torchcodec / torchaudio are not in
+    this image, so there is no reference output to compare with.  Checked instead: (1) `echo_op_resample` against a float64
+    evaluation of torchaudio's published sinc_interp_hann formula (conv1d with stride on the zero-padded signal); (2) analytic: a
+    1 kHz sine at 48 kHz comes out as a 1 kHz sine at 44.1 kHz (amplitude and phase, away from the edges); (3) `load_audio` on a
+    stereo 48 kHz WAV: channel mean, 44.1 kHz, peak scaled to <= 1, on the GPU."""
+    import math
+    from echo_tts_amd import audio_io as A
+    g = torch.Generator().manual_seed(1)
+    for o, n, length in ((48000, 44100, 5000), (16000, 44100, 1777), (44100, 24000, 4410)):
+        x = torch.randn((2, length), generator=g)
+        got = A.resample(x, o, n, device=DEV).cpu()
+        bank, up, down, width = A.sinc_resample_bank(o, n)
+        xp = torch.nn.functional.pad(x.double(), (width, width + down))
+        ref = torch.nn.functional.conv1d(xp[:, None], bank.double()[:, None], stride=down).transpose(1, 2).reshape(2, -1)
+        target = math.ceil(up * length / down)
+        assert got.shape == (2, target)
+        assert float((got.double() - ref[:, :target]).abs().max()) < 2e-5 * float(ref.abs().max())
+    sr, f0 = 48000, 1000.0
+    tt = torch.arange(48000, dtype=torch.float64) / sr
+    y = A.resample(torch.sin(2 * math.pi * f0 * tt).float()[None], sr, 44100, device=DEV).cpu()[0].double()
+    t2 = torch.arange(y.shape[0], dtype=torch.float64) / 44100
+    mid = slice(500, y.shape[0] - 500)
+    assert float((y[mid] - torch.sin(2 * math.pi * f0 * t2)[mid]).abs().max()) < 2e-3
+    wav = torch.stack([0.5 * torch.sin(2 * math.pi * 440 * tt), 2.5 * torch.sin(2 * math.pi * 440 * tt)]).float()     # mean peaks at 1.5
+    p = tmp_path / "v.wav"
+    import struct
+    payload = wav.t().contiguous().numpy().tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 2, sr, sr * 8, 8, 32)
+    p.write_bytes(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(payload)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt +
+                  b"data" + struct.pack("<I", len(payload)) + payload)
+    a = E.load_audio(str(p), max_duration=300)
+    assert a.is_cuda and a.shape == (1, 44100) and abs(float(a.abs().max()) - 1.0) < 2e-3
+    a2 = E.load_audio(str(p), max_duration=0.5)
+    assert a2.shape == (1, 22050)

@@ -221,3 +221,47 @@ def test_bench_host_logic(golden, monkeypatch):
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
     ids, tmask, x0 = None, None, None
     assert bench.dit_gemm_flops(1) > 1.3e14 and bench.free_port() > 0
+
+
+def test_audio_io_host_side(tmp_path):
+    """`load_audio`'s host half (reference inference.py:104-113; torchcodec / torchaudio are absent here, so this leg is PARITY UNPINNED and
+    checked against its own published formula): the RIFF/WAVE parser round-trips every sample format through `wav_bytes`-style files,
+    and the sinc / Hann filter bank has the properties the algorithm states (size, unit DC gain per phase, symmetry of phase 0)."""
+    import math
+    import struct
+    from echo_tts_amd import audio_io as A
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand((2, 1000), generator=g) * 2 - 1) * 0.9
+    p16 = tmp_path / "a16.wav"
+    p16.write_bytes(A.wav_bytes(x, 22050))
+    y, sr = A.read_wav(str(p16))
+    assert sr == 22050 and y.shape == (2, 1000) and float((y - x).abs().max()) <= 2.0 / 32768
+    y2, _ = A.read_wav(str(p16), max_duration=0.01)
+    assert y2.shape == (2, 220)
+    # float32 and 24-bit PCM files written by hand
+    def riff(tag, bits, payload, ch=2, rate=48000):
+        fmt = struct.pack("<HHIIHH", tag, ch, rate, rate * ch * bits // 8, ch * bits // 8, bits)
+        return b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(payload)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
+    pf = tmp_path / "f32.wav"
+    pf.write_bytes(riff(3, 32, x.t().contiguous().numpy().tobytes()))
+    yf, srf = A.read_wav(str(pf))
+    assert srf == 48000 and torch.equal(yf, x)
+    v24 = (x.t().contiguous() * (1 << 23)).round().clamp(-(1 << 23), (1 << 23) - 1).to(torch.int32).reshape(-1)
+    b24 = b"".join(int(v).to_bytes(3, "little", signed=True) for v in v24.tolist())
+    p24 = tmp_path / "p24.wav"
+    p24.write_bytes(riff(1, 24, b24))
+    y24, _ = A.read_wav(str(p24))
+    assert float((y24 - x).abs().max()) <= 2.0 ** -23 + 1e-7
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"OggS" + bytes(64))
+        A.read_wav(str(tmp_path / "bad.wav"))
+    # the filter bank (48 kHz -> 44.1 kHz: up 147, down 160; 24 kHz output leg: 44.1 -> 24 kHz: up 80, down 147)
+    for o, n in ((48000, 44100), (44100, 24000), (16000, 44100)):
+        bank, up, down, width = A.sinc_resample_bank(o, n)
+        gg = math.gcd(o, n)
+        assert (up, down) == (n // gg, o // gg) and bank.shape == (up, 2 * width + down)
+        assert width == math.ceil(6 * down / (min(up, down) * 0.99))
+        assert float((bank.double().sum(dim=1) - 1.0).abs().max()) < 2e-3          # a constant input stays (almost exactly) constant
+        c = bank[0, : 2 * width + 1]                                                  # phase 0 is centred on input sample `width`
+        assert torch.allclose(c, c.flip(0), atol=1e-7)
+    assert A.resample(x, 44100, 44100) is x                                           # equal rates: untouched, no GPU needed
