@@ -99,6 +99,58 @@ __global__ void __launch_bounds__(256) norm_kernel(const T* __restrict__ x, long
   }
 }
 
+// NORM_ADALN for the EchoDiT width (bf16, D = 512 * NC <= 2048): a wave keeps its share of the two modulation vectors in registers and
+// walks ROWS consecutive rows, all of whose loads are issued before the first is consumed.  The generic kernel above re-reads the 2 x D
+// modulation values for every row (8 KB through the L1 per 4 KB row at D = 2048) and has one 4 KB round trip per wave; same arithmetic,
+// same summation order, same bits.
+template <int NC, int ROWS>
+__global__ void __launch_bounds__(256) norm_adaln_rows_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, int rows,
+                                                              float eps, const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
+  constexpr int D = 512 * NC;
+  uint4 xr[ROWS][NC];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) xr[r][c] = *(const uint4*)(x + (long)row * ldx + (lane + 64 * c) * 8);
+  }
+  uint4 wa[NC], wb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { wa[c] = *(const uint4*)(w0 + (lane + 64 * c) * 8); wb[c] = *(const uint4*)(w1 + (lane + 64 * c) * 8); }
+  auto unpack = [](const uint4& r, float* f) __attribute__((always_inline)) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  };
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (row0 + r >= rows) break;
+    float v[NC][8];
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unpack(xr[r][c], v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += v[c][i] * v[c][i];
+    }
+    s2 = wave_sum(s2);
+    const float rs = rsqrtf(s2 / (float)D + eps);
+    bf16_t* yr = y + (long)(row0 + r) * ldy;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float a[8], b[8], o[8];
+      unpack(wa[c], a);
+      unpack(wb[c], b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(__fmul_rn(__fmul_rn(v[c][i], rs), a[i]), b[i]);
+      Chunk8<bf16_t>::store(yr + (lane + 64 * c) * 8, o);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ per-head RMSNorm + RoPE (HD = 128)
 // model.py:221-232 (q_norm/k_norm then _apply_rotary_half), model.py:138-142 (encoders: all heads),
 // model.py:289-291 (latent keys, positions 4*i).  One wave per (token, head); lane j owns the
@@ -405,6 +457,14 @@ hipError_t launch_norm(int mode, const T* x, long ldx, T* y, long ldy, int rows,
                        hipStream_t st) {
   if (D % 8 || D > 4096 || rows <= 0) return hipErrorInvalidValue;
   dim3 grid((rows + 3) / 4);
+  if constexpr (Num<T>::is_bf16) {
+    static const int rows_per_wave = getenv("ECHO_NORM_ROWS") ? atoi(getenv("ECHO_NORM_ROWS")) : 4;     // 1 = the generic kernel (A/B aid)
+    if (mode == NORM_ADALN && D == 2048 && rows >= 4096 && rows_per_wave > 1 && (ldx & 7) == 0 && (ldy & 7) == 0) {
+      if (rows_per_wave == 2) hipLaunchKernelGGL((norm_adaln_rows_kernel<4, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, x, ldx, y, ldy, rows, eps, w0, w1);
+      else hipLaunchKernelGGL((norm_adaln_rows_kernel<4, 4>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, y, ldy, rows, eps, w0, w1);
+      return hipGetLastError();
+    }
+  }
   switch (mode) {
     case NORM_ADALN: hipLaunchKernelGGL((norm_kernel<T, NORM_ADALN>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;
     case NORM_RMS_W: hipLaunchKernelGGL((norm_kernel<T, NORM_RMS_W>), grid, dim3(256), 0, st, x, ldx, y, ldy, rows, D, eps, w0, w1); break;

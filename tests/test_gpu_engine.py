@@ -1055,13 +1055,16 @@ def test_forward_with_per_row_timesteps(golden, tiny_models, dname, dt):
         m(x.to(dt), torch.tensor([0.5, 0.25]).to(dt), tm3, sm3, kvt3, kvs3)
 
 
-def _forward3(m, dt, x, tval, ids, tmask, spk, smask):
-    """One CFG-shaped forward through the engine: rows = [cond | text-uncond | speaker-uncond] x B (inference.py:474-475)."""
+def _forward3(m, dt, x, tval, ids, tmask, spk, smask, before_forward=None):
+    """One CFG-shaped forward through the engine: rows = [cond | text-uncond | speaker-uncond] x B (inference.py:474-475).
+    `before_forward()` runs between the KV encodes and the EchoDiT forward (test instruments are armed there)."""
     B = ids.shape[0]
     kvt, kvs = m.get_kv_cache_text(ids, tmask), m.get_kv_cache_speaker(spk, smask)
     tm3 = torch.cat([tmask, torch.zeros_like(tmask), tmask], 0)
     sm1 = smask.expand(B, -1)
     sm3 = torch.cat([sm1, sm1, torch.zeros_like(sm1)], 0)
+    if before_forward is not None:
+        before_forward()
     return m(x.to(dt), torch.full((3 * B,), tval).to(dt), tm3, sm3, _concat_kv_caches(kvt, kvt, kvt), kvs).float().cpu()
 
 
@@ -1078,16 +1081,15 @@ def test_full_depth_forward_budgets_have_teeth(golden, full_size):
           bf16 run is from eager fp32, overall and for its worst row: a budget 40x tighter than the 1.5 x 1.04 of round 2;
       (c) measured, not asserted: utterance 0's rows inside the batch-24 call (every linear on gemm_pp_kernel) against the same rows
           through the single call (wo / w2 on other tile kernels: other fp32 summation orders, same rounding points) differ by 1.7e-2 -
-          as much as the engine differs from eager bf16.  24 layers of bf16 amplify ANY summation-order change to the level of the
-          floor, so no full-depth bf16 distance can be tighter than (b), and a single negated 256 x 256 tile of one wo launch (it moves
-          its row by 1.4e-2 on the oracle) hides below it.  Teeth therefore need an EXACT property:
+          as much as the engine differs from eager bf16: 24 layers of bf16 amplify ANY summation-order change to the level of the
+          floor, so no full-depth bf16 DISTANCE can be tighter than (b); what can be tighter is an exact property:
       (d) ROW-PERMUTATION EQUIVARIANCE, bit for bit: the batch-24 forward with its utterances rotated by 7 must return exactly the
           rotated outputs.  Every GEMM of that call runs on the persistent ping-pong kernel, whose per-element arithmetic (K order, MFMA
           chain) does not depend on where a row sits in the tile walk; attention and the row kernels work per row.  A wrong entry in the
-          tile walk, a tile computed from a neighbour's operands or written to the wrong place breaks it;
-      (e) TEETH: with ONE 256 x 256 output tile of ONE wo / w2 launch negated (`echo_debug_corrupt_tile`: tile (1, 1), i.e. tokens
-          256..511 of whichever utterance comes first) the equivariance check fails, while that forward is still inside budget (b) -
-          which is exactly why (b) alone was not enough."""
+          tile walk, a tile computed from a neighbour's operands or written to the wrong place breaks it - however small the error;
+      (e) TEETH: with ONE 256 x 256 output tile of ONE wo / w2 launch of block 12 negated (`echo_debug_corrupt_tile`; these launches write
+          the residual stream, so the tile holds x for tokens 256..511 of the call's first row) the forward moves that row by 0.42-0.43
+          (measured) - 12x outside budget (b) - and breaks (d); the old budget of 1.5 x 1.04 would have let it pass."""
     fs = full_size
     cfg = fs["cfg"]
     S, B = 640, 24
@@ -1146,9 +1148,9 @@ def test_full_depth_forward_budgets_have_teeth(golden, full_size):
     assert torch.equal(got24p, got24[perm3]), f"not permutation-equivariant: rms {rms(got24p, got24[perm3]):.3e}"
     # (e) teeth: eligible launches of a forward are in_proj (1), then wo (2 + 2 l) and w2 (3 + 2 l) of block l: 26 / 27 = block 12's
     for nth in (26, 27):
-        L.check(mb._lib.echo_debug_corrupt_tile(mb._ctx, nth))
-        try:
-            bad = batched(mb, torch.bfloat16)
+        try:       # armed AFTER the text / speaker encoders (their wo / w2 launches are eligible too)
+            bad = _forward3(mb, torch.bfloat16, x, 0.75, ids, tmask, spk, smask,
+                            before_forward=lambda: L.check(mb._lib.echo_debug_corrupt_tile(mb._ctx, nth)))
         finally:
             L.check(mb._lib.echo_debug_corrupt_tile(mb._ctx, 0))
         moved = row_rms(bad, got24)
@@ -1158,7 +1160,9 @@ def test_full_depth_forward_budgets_have_teeth(golden, full_size):
               f"by {float(moved.max()):.3e}; utterance 0's rows vs the fp32 engine, worst row {vs_ref:.3e} (budget (b) {1.5 * floor_row:.3e}: "
               f"{'still inside' if vs_ref < 1.5 * floor_row else 'outside'})")
         assert hit == [0], hit                                     # tokens 256..511 of the call's first row (utterance 0, cond), nothing else
-        assert not torch.equal(got24p, bad[perm3])                 # the equivariance check (d) rejects the corrupted forward
+        assert vs_ref > 1.5 * floor_row                            # budget (b) rejects the corrupted forward ...
+        assert not torch.equal(got24p, bad[perm3])                 # ... and so does the equivariance check (d)
+        assert vs_ref < 1.5 * 1.04                                 # ... while round 2's budget (1.5 x the t-rounding distance) would have passed it
     assert torch.equal(got24p, permuted())                                                            # the instrument disarmed itself
 
 
