@@ -414,6 +414,71 @@ __global__ void __launch_bounds__(256) norm_adaln_fp8_kernel(const bf16_t* __res
   }
 }
 
+// the same with ROWS rows per wave and the modulation vectors in registers (D = 512 * NC; see norm_adaln_rows_kernel): same arithmetic, same bits
+template <int NC, int ROWS>
+__global__ void __launch_bounds__(256) norm_adaln_fp8_rows_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                                  float* __restrict__ scale, int rows, float eps, const bf16_t* __restrict__ w0,
+                                                                  const bf16_t* __restrict__ w1) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
+  constexpr int D = 512 * NC;
+  uint4 xr[ROWS][NC];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) xr[r][c] = *(const uint4*)(x + (long)row * ldx + (lane + 64 * c) * 8);
+  }
+  uint4 wa[NC], wb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { wa[c] = *(const uint4*)(w0 + (lane + 64 * c) * 8); wb[c] = *(const uint4*)(w1 + (lane + 64 * c) * 8); }
+  auto unpack = [](const uint4& r, float* f) __attribute__((always_inline)) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  };
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (row0 + r >= rows) break;
+    float v[NC][8];
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unpack(xr[r][c], v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += v[c][i] * v[c][i];
+    }
+    s2 = wave_sum(s2);
+    const float rs = rsqrtf(s2 / (float)D + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float a[8], b[8];
+      unpack(wa[c], a);
+      unpack(wb[c], b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[c][i] = Num<bf16_t>::rnd(__fadd_rn(__fmul_rn(__fmul_rn(v[c][i], rs), a[i]), b[i]));
+        amax = fmaxf(amax, fabsf(v[c][i]));
+      }
+    }
+    amax = wave_max(amax);
+    const bool nz = amax > 0.0f;
+    const float inv = nz ? __fdiv_rn(448.0f, amax) : 1.0f;
+    if (lane == 0) scale[row0 + r] = nz ? __fdiv_rn(amax, 448.0f) : 1.0f;
+    uint8_t* qr = q + (long)(row0 + r) * ldq;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+      *(uint2*)(qr + (lane + 64 * c) * 8) = uint2{(unsigned)lo, (unsigned)hi};
+    }
+  }
+}
+
 // bf16 rows -> OCP e4m3 bytes + one fp32 scale per row (the A / W operands of the fp8 ping-pong GEMM): one wave per row,
 // scale = amax / 448 (1 for an all-zero row), q = e4m3(x * (448 / amax)), round-to-nearest-even by v_cvt_pk_fp8_f32.  The row is
 // read twice (the second pass hits L2); 8 elements per lane and step: 16 bytes in, 8 bytes out.  K % 8 == 0.
@@ -458,9 +523,9 @@ hipError_t launch_norm(int mode, const T* x, long ldx, T* y, long ldy, int rows,
   if (D % 8 || D > 4096 || rows <= 0) return hipErrorInvalidValue;
   dim3 grid((rows + 3) / 4);
   if constexpr (Num<T>::is_bf16) {
-    static const int rows_per_wave = getenv("ECHO_NORM_ROWS") ? atoi(getenv("ECHO_NORM_ROWS")) : 4;     // 1 = the generic kernel (A/B aid)
+    static const int rows_per_wave = getenv("ECHO_NORM_ROWS") ? atoi(getenv("ECHO_NORM_ROWS")) : 2;     // 1 = the generic kernel (A/B aid); measured (tools/bench_norm.py, M = 15360 / 46080): 29.1 / 88.3 us generic, 21.3 / 67.2 with 2 rows per wave, 22.6 / 70.2 with 4
     if (mode == NORM_ADALN && D == 2048 && rows >= 4096 && rows_per_wave > 1 && (ldx & 7) == 0 && (ldy & 7) == 0) {
-      if (rows_per_wave == 2) hipLaunchKernelGGL((norm_adaln_rows_kernel<4, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, x, ldx, y, ldy, rows, eps, w0, w1);
+      if (rows_per_wave != 4) hipLaunchKernelGGL((norm_adaln_rows_kernel<4, 2>), dim3((rows + 7) / 8), dim3(256), 0, st, x, ldx, y, ldy, rows, eps, w0, w1);
       else hipLaunchKernelGGL((norm_adaln_rows_kernel<4, 4>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, y, ldy, rows, eps, w0, w1);
       return hipGetLastError();
     }
@@ -557,6 +622,12 @@ hipError_t launch_softmax_f32(float* s, long ld, int rows_per_batch, int nbatch,
 hipError_t launch_norm_adaln_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int D, float eps, const void* scale1p,
                                  const void* shift, hipStream_t st) {
   if (rows < 1 || D < 8 || (D & 7) || D > 4096 || (ldx & 7) || (ldq & 7)) return hipErrorInvalidValue;
+  static const int rows_per_wave = getenv("ECHO_NORM_ROWS") ? atoi(getenv("ECHO_NORM_ROWS")) : 2;
+  if (D == 2048 && rows >= 4096 && rows_per_wave > 1) {
+    hipLaunchKernelGGL((norm_adaln_fp8_rows_kernel<4, 2>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale,
+                       rows, eps, (const bf16_t*)scale1p, (const bf16_t*)shift);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(norm_adaln_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale,
                      rows, D, eps, (const bf16_t*)scale1p, (const bf16_t*)shift);
   return hipGetLastError();

@@ -408,6 +408,39 @@ def test_norm_modes(dt, D):
             assert (y - ref).abs().max().item() < 2e-5, mode
 
 
+@pytest.mark.parametrize("rows", [4096, 5003, 15360])
+def test_norm_adaln_rows_per_wave_kernel_equals_the_generic_one(rows):
+    """AdaLN-apply at the EchoDiT width with >= 4096 rows runs norm_adaln_rows_kernel (two rows per wave, the modulation vectors in
+    registers; +35 % bandwidth, tools/bench_norm.py).  Same arithmetic and summation order as the generic kernel: its output must be BIT-equal
+    to the generic kernel's on the same rows (launched in slices of < 4096 rows, which take the generic path), incl. a row count that is
+    not a multiple of the 8 rows of a workgroup, strided inputs, and it must stay within 1 bf16 ulp of the torch evaluation."""
+    D = 2048
+    xbig = rnd(rows, D + 64, dtype=torch.bfloat16, seed=7)
+    x = xbig[:, :D]                                        # row pitch D + 64: the kernels take ldx
+    w0, w1 = (1 + 0.1 * rnd(D, seed=1)).bfloat16(), (0.1 * rnd(D, seed=2)).bfloat16()
+    y = torch.zeros((rows, D), dtype=torch.bfloat16, device=DEV)
+    L.check(U.lib().echo_op_norm(L.ECHO_BF16, 0, x.data_ptr(), D + 64, y.data_ptr(), D, rows, D, 1e-5, w0.data_ptr(), w1.data_ptr(), U.stream()))
+    yg = torch.zeros_like(y)
+    for r0 in range(0, rows, 2048):
+        n = min(2048, rows - r0)
+        L.check(U.lib().echo_op_norm(L.ECHO_BF16, 0, x[r0:].data_ptr(), D + 64, yg[r0:].data_ptr(), D, n, D, 1e-5, w0.data_ptr(), w1.data_ptr(), U.stream()))
+    assert torch.equal(y, yg)
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w0.float() + w1.float()).bfloat16()
+    U.bf16_close(y, ref, ulps=1.01, atol=1e-3)
+    # the fp8 engine's fused variant (norm + e4m3 row quantisation), same slicing: codes and scales bit-equal
+    q, sc = torch.zeros((rows, D), dtype=torch.uint8, device=DEV), torch.zeros((rows,), dtype=torch.float32, device=DEV)
+    qg, sg = torch.zeros_like(q), torch.zeros_like(sc)
+    L.check(U.lib().echo_op_norm_adaln_fp8(x.data_ptr(), D + 64, q.data_ptr(), D, sc.data_ptr(), rows, D, 1e-5, w0.data_ptr(), w1.data_ptr(), U.stream()))
+    for r0 in range(0, rows, 2048):
+        n = min(2048, rows - r0)
+        L.check(U.lib().echo_op_norm_adaln_fp8(x[r0:].data_ptr(), D + 64, qg[r0:].data_ptr(), D, sg[r0:].data_ptr(), n, D, 1e-5, w0.data_ptr(),
+                                               w1.data_ptr(), U.stream()))
+    assert torch.equal(q, qg) and torch.equal(sc, sg)
+    q2, s2 = U.quant_rows_fp8(y)                          # = norm kernel followed by the row quantiser
+    assert torch.equal(q, q2) and torch.equal(sc, s2)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_headnorm_rope_half_heads(dt):
     """q_norm/k_norm + RoPE on heads [0, H/2) at positions start_pos + s (model.py:199-232)."""
