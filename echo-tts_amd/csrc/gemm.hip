@@ -169,9 +169,15 @@ __device__ __forceinline__ int slab_pos(int ml, int chunk) {
 struct EpiProf { unsigned long long t_bar1 = 0, t_put = 0, t_bar2 = 0, t_rw = 0; };
 #define EPI_STAMP(var) do { if constexpr (PROF) { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); prof->var += n__ - last__; last__ = n__; } } while (0)
 
-template <typename T, bool SWIGLU, int BM, int BN, int NT, bool DRAIN, bool PROF = false, typename PutFn>
+// NTAIL: 0 = every tail, 1 = the row-layout tails only (generic / SwiGLU): instantiations launched without split-K and without the fused QKV tail
+// do not carry those branches (and their registers) at all - see gemm_pp_kernel's TAIL
+template <typename T, bool SWIGLU, int BM, int BN, int NT, bool DRAIN, bool PROF = false, int NTAIL = 0, typename PutFn>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, int tid, int tile_m, int tile_n, int tiles_m, int zo, int zi,
                                               long c_z, int split, PutFn put, EpiProf* prof = nullptr) {
+  // tid / tile coordinates behind an opaque asm: the epilogue's per-thread address arithmetic is then computed HERE, after the K loop, instead
+  // of being hoisted above it and kept in registers through it (the 256 x 192 split3 instantiation spilled 30 VGPRs for that)
+  asm volatile("" : "+v"(tid));
+  asm volatile("" : "+s"(tile_m), "+s"(tile_n));
   unsigned long long last__ = 0;
   if constexpr (PROF) last__ = __builtin_amdgcn_s_memtime();
   T* C = (T*)p.C + c_z;
@@ -189,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
   const int g_chunk = tid % CPR, g_r0 = tid / CPR;
   const int g_n0 = tile_n * BN + g_chunk * 4;
   const bool g_col_ok = tid < NTA && g_n0 < p.N;
-  const bool generic = !(p.ksplit > 1) && !SWIGLU && !p.qkv_mode;
+  const bool generic = NTAIL == 1 ? !SWIGLU : (!(p.ksplit > 1) && !SWIGLU && !p.qkv_mode);
   float rs_next[ITER][4];
 #pragma unroll
   for (int k = 0; k < ITER; ++k)
@@ -216,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
     __builtin_amdgcn_s_barrier();
     EPI_STAMP(t_bar2);
     const int mrow0 = tile_m * BM + pass * 32;
-    if (p.ksplit > 1) {
+    if (NTAIL == 0 && p.ksplit > 1) {
       // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
       float* ws = (float*)p.ws + ((long)split * tiles_m * BM + mrow0) * (long)p.Npad + (long)tile_n * BN;
 #pragma unroll
@@ -238,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         const f32x4 b4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, b * 8 + 4 + q) * 4);
         swiglu_tail<T>(p, m, j0, a4, b4, C);
       }
-    } else if (p.qkv_mode) {
+    } else if (NTAIL == 0 && p.qkv_mode) {
       const int D = p.qkv_D;
       const int sec = (tile_n * BN) / D;           // the whole tile lies in one of q | k | v | gate (D % BN == 0)
       if (sec == 2) {
@@ -332,7 +338,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
 // product is evaluated as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (relative error ~2^-16 per
 // product, ~1e-5 on sums): 16/3 times the fp32-MFMA rate.  Used for the Fish S1-DAC decoder whose 1e-4 waveform
 // tolerance leaves three orders of magnitude of head room; the parity-mode DiT keeps the exact fp32 MFMA.
-template <typename T, bool SWIGLU, typename CF, bool SPLIT3>
+template <typename T, bool SWIGLU, typename CF, bool SPLIT3, int NTAIL = 0>
 __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = KBYTES / (int)sizeof(T);
@@ -545,7 +551,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
 
   // ---- epilogue (gemm_epilogue): this wave's accumulators of one 32-row pass go into the LDS slab
   const int fr_ = fr, fh_ = fh;
-  gemm_epilogue<T, SWIGLU, BM, BN, CF::NT, true>(p, (float*)smem, tid, tile_m, tile_n, tiles_m, zo, zi, c_z, split, [&](int pass, float* slab) {
+  gemm_epilogue<T, SWIGLU, BM, BN, CF::NT, true, false, NTAIL>(p, (float*)smem, tid, tile_m, tile_n, tiles_m, zo, zi, c_z, split, [&](int pass, float* slab) {
     constexpr int CPR = BN / 4;
     if (wm == pass / TM) {
       const int tm_sel = pass % TM;
@@ -671,7 +677,13 @@ __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, flo
 // FP8: A and W are OCP e4m3 bytes (K-tile = 128 elements = the same 128-byte rows, so staging, ring and phases are unchanged);
 // a phase is 8 v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 FLOPs per cycle) on fragments of 32
 // consecutive K bytes per lane, and the accumulators are multiplied by a_scale[m] * w_scale[n] before the bf16 tails.
-template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false>
+// TAIL: which epilogues an instantiation carries.  One kernel with every tail (split-K slabs, fused QKV, the row-layout tails) needs the
+// union of their registers: the all-tails build of round 2 had 71 VGPR + 108 SGPR spills (272 bytes of scratch per lane) around its tile
+// hand-over while the SwiGLU-only instantiation had 2 and the epilogue-less timing build none.  TAIL_ROWS = the row-layout tails only (plain
+// store, column scale + residual: wo / w2, and the generic bias / activation form), TAIL_QKV = the fused QKV(G) tail only, TAIL_ALL = everything
+// (split-K and the diagnostic builds).  The launcher picks the instantiation from the arguments.
+enum { TAIL_ALL = 0, TAIL_ROWS = 1, TAIL_QKV = 2, TAIL_FAST = 3 };      // TAIL_FAST: y = T(acc) [* colscale] [+ residual] only (QKV-less plain store, wo, w2)
+template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false, int TAIL = TAIL_ALL>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -708,6 +720,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   // part of the address is a 32-bit byte offset that only changes with the output tile; everything that moves inside a
   // tile (K position, tap) and the batch offset are wave-uniform and live in the 64-bit scalar cursors.
   unsigned voff[4][2];
+  const unsigned lda_b = (unsigned)(p.lda * ES), ldw_b = (unsigned)(p.ldw * ES);      // row pitches in bytes
   auto set_stage_tile = [&](int v) __attribute__((always_inline)) {
     int tm, tn;
     tile_of(v, tm, tn);
@@ -720,11 +733,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         if (j == 0 || j == 3) {                                // A: unit row = wave row (ur >> 5) x 32 rows of this m-half
           int gm = tm * BM + (ur >> 5) * 64 + (j == 3 ? 32 : 0) + (ur & 31);
           gm = gm < p.M ? gm : p.M - 1;
-          voff[j][i] = (unsigned)((long)gm * p.lda * ES + chunk * 16);
+          voff[j][i] = (unsigned)gm * lda_b + (unsigned)(chunk * 16);     // 32-bit on purpose (launch_sw refuses operands whose row offsets need more)
         } else {                                               // W: unit row = wave column (ur >> 6) x 64 rows of this n-half
           int gn = tn * BN + (ur >> 6) * 128 + (j == 2 ? 64 : 0) + (ur & 63);
           gn = gn < p.Npad ? gn : p.Npad - 1;
-          voff[j][i] = (unsigned)((long)gn * p.ldw * ES + chunk * 16);
+          voff[j][i] = (unsigned)gn * ldw_b + (unsigned)(chunk * 16);
         }
       }
   };
@@ -886,14 +899,19 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   // ---- epilogue pieces
   float* const my = (float*)(smem + 2 * KTILE) + wid * 1024;     // this wave's private 16 x 64 fp32 transposition area
   T* const C = (T*)p.C + c_z;
+  // Epilogue-local copies of the lane coordinates, re-derived behind an opaque asm at every tile's epilogue: hipcc otherwise hoists the
+  // epilogue's per-lane address arithmetic (LDS transposition addresses, row offsets) out of the tile loop and keeps it in registers ACROSS the
+  // K loop, which already sits at 256 - the all-tails build carried 71 VGPR spills (scratch stores / loads around every tile hand-over, in the
+  // same in-order vmcnt stream as the LDS-DMA units) for it.
+  int lane_e = lane, fr_e = fr, fg_e = fg;
   // 16 rows x 64 columns held as v[c][r] = X[row fr][col 16 c + 4 fg + r]  ->  fn(row, c8, y[8]) with
   // y = X[row][8 c8 .. 8 c8 + 7], row = 8 it + lane / 8, c8 = lane % 8.  Same-wave LDS traffic is executed in order.
   auto rows = [&](const f32x4 (&v)[4], auto&& fn) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr * 16 + ((c * 4 + fg) ^ fr)) * 4) = v[c];
+    for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = v[c];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+      const int row = it * 8 + (lane_e >> 3), c8 = lane_e & 7;
       const f32x4 a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
       const f32x4 b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
       float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -929,16 +947,22 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     if (wid < 4) __builtin_amdgcn_s_barrier();    // level again: both groups run their epilogues side by side
     if constexpr (DIAG == 5) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_loop += n - t_l0; t_l0 = n; ++n_tiles; }
 
+    lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    fr_e = lane_e & 15; fg_e = lane_e >> 4;
+    // the tile coordinates too: everything the epilogue derives from them (64-bit row offsets of C / the residual, ...) is computed HERE,
+    // behind the K loop, instead of at the top of the iteration and carried through it
+    asm volatile("" : "+s"(tile_m), "+s"(tile_n));
     const int m_base = tile_m * BM + wm * 64;      // + 16 i + row
     const int n_base = tile_n * BN + wn * 128;     // + 64 h + 8 c8 (W-row index of the accumulator columns)
     if constexpr (FP8) {
-      // dequantise in the accumulator layout: lane holds C[m_base + 16 i + fr][n_base + 16 jn + 4 fg + r]
+      // dequantise in the accumulator layout: lane_e holds C[m_base + 16 i + fr_e][n_base + 16 jn + 4 fg_e + r]
       float sa[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr; sa[i] = p.a_scale ? p.a_scale[m < p.M ? m : p.M - 1] : p.a_scale_const; }
+      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr_e; sa[i] = p.a_scale ? p.a_scale[m < p.M ? m : p.M - 1] : p.a_scale_const; }
 #pragma unroll
       for (int jn = 0; jn < 8; ++jn) {
-        const int n0 = n_base + 16 * jn + 4 * fg;
+        const int n0 = n_base + 16 * jn + 4 * fg_e;
         const f32x4 sw = *(const f32x4*)(p.w_scale + (n0 + 3 < p.Npad ? n0 : p.Npad - 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -951,7 +975,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
-    } else if (p.ksplit > 1) {
+    } else if (TAIL == TAIL_ALL && p.ksplit > 1) {
       // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
       float* ws = (float*)p.ws + (long)split * tiles_m * BM * (long)p.Npad;
 #pragma unroll
@@ -969,8 +993,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           });
         }
     } else if constexpr (SWIGLU) {
-      // W rows come in 32-row groups [16 x w1 | 16 x w3]: fragments jn = 2k, 2k + 1 of one lane are the (a, b) pairs
-      // of output columns 16 k + 4 fg + r (model.py:307); 64 output columns per wave
+      // W rows come in 32-row groups [16 x w1 | 16 x w3]: fragments jn = 2k, 2k + 1 of one lane_e are the (a, b) pairs
+      // of output columns 16 k + 4 fg_e + r (model.py:307); 64 output columns per wave
       const int j_base = tile_n * (BN / 2) + wn * 64;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1002,22 +1026,22 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           }
         });
       }
-    } else if (p.qkv_mode) {
+    } else if ((TAIL == TAIL_ALL || TAIL == TAIL_QKV) && (TAIL == TAIL_QKV || p.qkv_mode)) {
       const int D = p.qkv_D;
       const int sec = (tile_n * BN) / D;            // the whole tile lies in one of q | k | v | gate (D % 256 == 0)
       if (sec == 2) {
         // V: Vt[b][h * 128 + d][token]; this wave holds 64 tokens x the 128 d of one head.  Per 16 d (fragment jn) the
-        // four token fragments go through the private area as [d][token] and leave as 8 tokens per lane.
+        // four token fragments go through the private area as [d][token] and leave as 8 tokens per lane_e.
         const int hd_base = n_base - 2 * D;
 #pragma unroll
         for (int jn = 0; jn < 8; ++jn) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) my[(4 * fg + r) * 64 + 16 * i + fr] = Num<T>::rnd(acc[i][jn][r]);
+            for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + 16 * i + fr_e] = Num<T>::rnd(acc[i][jn][r]);
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
-            const int dl = it * 8 + (lane >> 3), t8 = lane & 7;
+            const int dl = it * 8 + (lane_e >> 3), t8 = lane_e & 7;
             const f32x4 a = *(const f32x4*)(my + dl * 64 + 8 * t8);
             const f32x4 b = *(const f32x4*)(my + dl * 64 + 8 * t8 + 4);
             const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -1043,7 +1067,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         // instead of one per 16-column fragment (in-situ: the loads issued one at a time cost 91 us of a 543 us launch at
         // M = 15360).  Larger batches (a whole row, or a row ahead) pushed the kernel over its 256 registers and spilled
         // the accumulators.
-        const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg + r)
+        const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg_e + r)
         const bool do_rope = sec < 2 && (nd0 >> 7) < p.rope_heads;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1062,7 +1086,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           const float4* rp = nullptr;
           if (sec < 2) {
             // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
-            // lane, the other 96 in lanes fr + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
+            // lane_e, the other 96 in lanes fr_e + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
             float ss = 0.f;
 #pragma unroll
             for (int jn = 0; jn < 8; ++jn)
@@ -1071,16 +1095,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int m = m_base + 16 * i + fr;
+            const int m = m_base + 16 * i + fr_e;
             const int pos = p.pos0 + m % p.qkv_S;
-            rp = (const float4*)((const float2*)p.rope + (long)pos * 64) + fg;     // pairs 8 jn + 2 fg, + 1
+            rp = (const float4*)((const float2*)p.rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (sec < 2) {
               float4 cs[4];
               uint2 w4p[4];
-              const T* wp = (const T*)p.qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg;
+              const T* wp = (const T*)p.qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg_e;
 #pragma unroll
               for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
               if (do_rope) {
@@ -1113,11 +1137,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           }
         }
       }
-    } else if (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7) {
+    } else if (TAIL == TAIL_QKV) {
+      // (this instantiation is only launched with qkv_mode set)
+    } else if (TAIL == TAIL_FAST || (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7)) {
       // fast path of the big EchoDiT linears: y = T(acc) [* colscale] [+ residual].  Fully unrolled (static accumulator
-      // reads), addresses hoisted: one 64-bit per-lane offset per tile, everything else wave-uniform; the residual rows of
+      // reads), addresses hoisted: one 64-bit per-lane_e offset per tile, everything else wave-uniform; the residual rows of
       // a piece are requested before its LDS round trip; interior tiles skip the per-element bounds tests.
-      const int row0 = lane >> 3, c8 = lane & 7;
+      const int row0 = lane_e >> 3, c8 = lane_e & 7;
       const bool full = m_base + 64 <= p.M && n_base + 128 <= p.N;          // wave-uniform
       const long off0 = (long)(m_base + row0) * p.ldc + n_base + 8 * c8;
       const long roff0 = (long)(m_base + row0) * p.ldres + n_base + 8 * c8;
@@ -1150,13 +1176,19 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           const int pc = 2 * i + h;
           if (pc + 1 < 8) load_res(pc + 1, rq[(pc + 1) & 1]);
           const uint4 (&rr)[2] = rq[pc & 1];
+          if constexpr (DIAG != 9) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr * 16 + ((c * 4 + fg) ^ fr)) * 4) = acc[i][4 * h + c];
+          for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = acc[i][4 * h + c];
+          }
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int row = it * 8 + row0;
-            const f32x4 a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
-            const f32x4 b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+            f32x4 a, b;
+            if constexpr (DIAG == 9) { a = acc[i][4 * h + 2 * it]; b = acc[i][4 * h + 2 * it + 1]; }      // timing experiment: no LDS round trip (wrong layout)
+            else {
+              a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
+              b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+            }
             float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e]);
@@ -1171,10 +1203,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
               for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] + r[e]);
             }
             const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+            if constexpr (DIAG == 8) {           // timing experiment: the fast-path epilogue without its global stores
+              const uint4 pk = pack8_bf16(y);
+              asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+            } else
             if (full || (m < p.M && n0 < p.N)) *(uint4*)(C + off0 + (long)(16 * i + 8 * it) * p.ldc + 64 * h) = pack8_bf16(y);
           }
         }
-    } else {
+    } else if constexpr (TAIL != TAIL_FAST) {
       // the tail is emitted once (runtime loop over the 8 pieces); the accumulators of piece 2 i + h are picked by
       // static register reads pinned with an empty asm (merged stores would turn `acc` into a scratch array)
 #pragma unroll 1
@@ -1250,10 +1286,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs p, in
   }
 }
 
+template <typename T, bool SW, typename CF, bool SPLIT3, int NTAIL>
+hipError_t launch_cfg_tail(const GemmArgs& g, hipStream_t st);
+
 template <typename T, bool SW, typename CF, bool SPLIT3 = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
+  static const bool split = getenv("ECHO_NT_TAILS") ? atoi(getenv("ECHO_NT_TAILS")) != 0 : true;      // 0: the all-tails instantiation everywhere (A/B aid)
+  if (split && g.ksplit <= 1 && !g.qkv_mode) return launch_cfg_tail<T, SW, CF, SPLIT3, 1>(g, st);
+  return launch_cfg_tail<T, SW, CF, SPLIT3, 0>(g, st);
+}
+
+template <typename T, bool SW, typename CF, bool SPLIT3, int NTAIL>
+hipError_t launch_cfg_tail(const GemmArgs& g, hipStream_t st) {
   static std::atomic<unsigned long long> prepared{0};
-  auto kern = gemm_nt_kernel<T, SW, CF, SPLIT3>;
+  auto kern = gemm_nt_kernel<T, SW, CF, SPLIT3, NTAIL>;
   if (hipError_t e = ensure_dyn_lds((const void*)kern, CF::SMEM, prepared); e != hipSuccess) return e;
   const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = ((SW ? g.Npad : g.N) + CF::BN - 1) / CF::BN;
   const int ks = g.ksplit > 1 ? g.ksplit : 1;
@@ -1284,13 +1330,31 @@ int pp_num_cus() {
   return n;
 }
 
+template <bool SW, int DIAG, int LEAD, bool FP8, int TAIL>
+hipError_t launch_pp_tail(const GemmArgs& g_in, hipStream_t st);
+
 template <bool SW, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false>
-hipError_t launch_pp(const GemmArgs& g_in, hipStream_t st) {
+hipError_t launch_pp(const GemmArgs& g, hipStream_t st) {
+  // the production builds (DIAG 0, default LEAD) come in tail-specialised instantiations (see gemm_pp_kernel); ECHO_PP_TAILS=0 forces the
+  // all-tails build (A/B aid)
+  if constexpr (DIAG == 0 && LEAD == PP_LEAD && !SW) {
+    static const bool split = getenv("ECHO_PP_TAILS") ? atoi(getenv("ECHO_PP_TAILS")) != 0 : true;
+    if (split && g.ksplit <= 1) {
+      if (g.qkv_mode) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_QKV>(g, st);
+      if (g.acc_scale == 1.0f && !g.bias && g.div == 0.0f && g.act == 0 && !g.vec_mod) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_FAST>(g, st);
+      return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_ROWS>(g, st);
+    }
+  }
+  return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_ALL>(g, st);
+}
+
+template <bool SW, int DIAG, int LEAD, bool FP8, int TAIL>
+hipError_t launch_pp_tail(const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   static const int env_gn = getenv("ECHO_PP_GN") ? atoi(getenv("ECHO_PP_GN")) : 0;
   if (g.pp_gn <= 0 && env_gn > 0) g.pp_gn = env_gn;
   static std::atomic<unsigned long long> prepared{0};
-  auto kern = gemm_pp_kernel<SW, DIAG, LEAD, FP8>;
+  auto kern = gemm_pp_kernel<SW, DIAG, LEAD, FP8, TAIL>;
   constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
   if (hipError_t e = ensure_dyn_lds((const void*)kern, SMEM, prepared); e != hipSuccess) return e;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.Npad + 255) / 256;
@@ -1345,7 +1409,7 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
     const long es = g.fp8 ? 1 : 2;
     if ((long)(g.M - 1) * g.lda * es + 128 >= (1L << 32) || (long)(g.Npad - 1) * g.ldw * es + 128 >= (1L << 32)) return hipErrorInvalidValue;
   }
-  if (g.fp8 && g.cfg != 5) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel only
+  if (g.fp8 && g.cfg != 5 && g.cfg != 104 && g.cfg != 105 && g.cfg != 108) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel (and three of its diagnostic builds) only
   if (g.c8 && !(g.fp8 && SW && g.ksplit <= 1 && (g.c8_ld & 7) == 0 && g.c8_inv > 0.0f)) return hipErrorInvalidValue;   // e4m3 output: SwiGLU tail of the fp8 kernel only
   if (g.cfg == 5) {
     if constexpr (Num<T>::is_bf16) {
@@ -1358,6 +1422,13 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
   }
   if (g.cfg >= 100) {   // timing experiments (tools/bench_gemm.py --diag): wrong results by construction
     if constexpr (Num<T>::is_bf16 && !SW) {
+      if (g.fp8) {      // tools/prof_fp8.py: no epilogue (wrong results) / cycle sums per wave / per-phase cycle sums
+        if ((!g.a_scale && !(g.a_scale_const > 0.0f)) || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
+        if (g.cfg == 104) return launch_pp<false, 4, PP_LEAD, true>(g, st);
+        if (g.cfg == 105) return launch_pp<false, 5, PP_LEAD, true>(g, st);
+        if (g.cfg == 108) return launch_pp<false, 6, PP_LEAD, true>(g, st);
+        return hipErrorInvalidValue;
+      }
       if (g.cfg == 101) return launch_pp<false, 1>(g, st);
       if (g.cfg == 102) return launch_pp<false, 2>(g, st);
       if (g.cfg == 103) return launch_pp<false, 3>(g, st);
@@ -1365,6 +1436,8 @@ hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
       if (g.cfg == 105) return launch_pp<false, 5>(g, st);
       if (g.cfg == 108) return launch_pp<false, 6>(g, st);
       if (g.cfg == 109) return launch_pp<false, 7>(g, st);
+      if (g.cfg == 110) return launch_pp<false, 8>(g, st);      // fast-path epilogue without global stores
+      if (g.cfg == 111) return launch_pp<false, 9>(g, st);      // fast-path epilogue without the LDS round trip
       if (g.cfg == 106) return launch_pp<false, 0, 6>(g, st);
       if (g.cfg == 107) return launch_pp<false, 0, 4>(g, st);
     }
@@ -1394,7 +1467,7 @@ hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
   constexpr int KE = KBYTES / (int)sizeof(T);
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
       g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 109)))
+      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 111)))
     return hipErrorInvalidValue;
   if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
     return hipErrorInvalidValue;
