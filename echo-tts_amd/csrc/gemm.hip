@@ -615,6 +615,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(con
 #ifndef PP_GN
 #define PP_GN 4
 #endif
+#ifndef PP_RES_AHEAD
+#define PP_RES_AHEAD 1
+#endif
 template <int V> struct IC { static constexpr int value = V; };
 
 __device__ __forceinline__ uint4 pack8_bf16(const float* y) {
@@ -1158,7 +1161,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
       }
       // the residual chunks of piece pc + 1 are requested before piece pc goes through LDS and is stored: a load issued
       // behind a store would wait for that store's round trip too (one in-order vmcnt), once per piece
-      uint4 rq[2][2];
+      // RES_AHEAD pieces of residual are in flight (measured round 3 with 1 / 3 / 7: no difference, wo 446 / 432-445 / 437-449 us at M = 46080)
+      constexpr int RES_AHEAD = PP_RES_AHEAD, RQN = RES_AHEAD + 1;
+      uint4 rq[RQN][2];
       auto load_res = [&](int pc, uint4 (&r)[2]) __attribute__((always_inline)) {
         const int i = pc >> 1, h = pc & 1;
 #pragma unroll
@@ -1168,14 +1173,15 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           if (resp && (full || (m < p.M && n0 < p.N))) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
         }
       };
-      load_res(0, rq[0]);
+#pragma unroll
+      for (int a = 0; a < RES_AHEAD && a < 8; ++a) load_res(a, rq[a % RQN]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pc = 2 * i + h;
-          if (pc + 1 < 8) load_res(pc + 1, rq[(pc + 1) & 1]);
-          const uint4 (&rr)[2] = rq[pc & 1];
+          if (pc + RES_AHEAD < 8) load_res(pc + RES_AHEAD, rq[(pc + RES_AHEAD) % RQN]);
+          const uint4 (&rr)[2] = rq[pc % RQN];
           if constexpr (DIAG != 9) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = acc[i][4 * h + c];
