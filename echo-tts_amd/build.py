@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libechohip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "dac.hip", "postproc.hip", "engine.hip"]
+SOURCES = ["gemm_pp.hip", "gemm.hip", "gemm_f32.hip", "attention.hip", "elementwise.hip", "dac.hip", "postproc.hip", "engine.hip"]
 # attention.hip: the one-wave-per-SIMD kernel places every VALU instruction in an MFMA gap by hand; SLP vectorisation would turn its
 # scalar fp32 adds into v_pk_add_f32 plus the v_mov shuffles that feed them (cdna_hip_programming.md Appendix B, pitfalls)
 EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}

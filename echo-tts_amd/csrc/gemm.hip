@@ -14,1478 +14,19 @@
 // which makes every fragment read conflict-free (cdna_hip_programming.md §5.4 rule 21, §5.5 T2).  Operands are swapped
 // into the MFMA (W rows -> MFMA rows, activation rows -> MFMA columns) so that each lane ends up with 4 consecutive
 // output columns of one output row: the SwiGLU pair (w1, w3) and the RoPE pairs live in one lane.
-#include "common.h"
-#include <cstdlib>
+
+#include "gemm_tile.h"
 
 void gemm_args_init(GemmArgs* g) {
   memset(g, 0, sizeof(*g));
   g->taps = 1; g->nbatch = 1; g->nbi = 1; g->acc_scale = 1.0f; g->store_main = 1;
 }
 
-namespace {
-
-constexpr int KBYTES = 128;   // K step: 128 bytes per row (64 bf16 / 32 fp32)
-#ifndef DMA_SPREAD_DEN
-#define DMA_SPREAD_DEN 2
-#endif
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T>
-__device__ __forceinline__ float vec_at(const void* p, long i) { return Num<T>::ld(((const T*)p)[i]); }
-
-// Tile configuration: BM x BN output tile, NWM x NWN waves (each wave (BM/NWM) x (BN/NWN)), STAGES LDS buffers.
-template <int BM_, int BN_, int NWM_, int NWN_, int STAGES_>
-struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, NWM = NWM_, NWN = NWN_, STAGES = STAGES_;
-  static constexpr int NW = NWM * NWN, NT = NW * 64;
-  static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
-  static constexpr int STAGE_BYTES = (BM + BN) * KBYTES;
-  static constexpr int SMEM = STAGES * STAGE_BYTES;
-  static constexpr int PIECES = (BM + BN) / 8;          // 1 KiB DMA pieces (8 rows x 128 B) per stage
-  static constexpr int PPW = PIECES / NW;               // pieces per wave
-  static constexpr int WAVES_PER_SIMD = NW / 4 * (SMEM <= 80 * 1024 ? 2 : 1);
-  static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
-  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert(32 * BN * 4 <= SMEM, "epilogue slab must fit");
-};
-
-// ---- fused tail (one rounding to T wherever eager PyTorch materialises a tensor)
-// Split into the loads (per-column vectors and the residual row) and the arithmetic + stores: CDNA4 has ONE in-order vmcnt
-// for loads and stores, so a load issued behind a store waits for that store's round trip too.  The epilogues request the
-// operands of output chunk k + 1 before they store chunk k.
-struct TailCols { float bias[4], cs[4], al[4], ial[4]; };   // per-column operands of 4 consecutive output columns (ial = 1 / (alpha + 1e-9))
-
-template <typename T>
-__device__ __forceinline__ void gemm_tail_cols(const GemmArgs& p, int n0, int zo, int zi, TailCols& t) {
-  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
-  if (p.bias) {
-    const long bo = zo * p.bias_bo + zi * p.bias_bi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t.bias[i] = vec_at<T>(p.bias, bo + nv + i);
-  }
-  if (p.colscale) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t.cs[i] = vec_at<T>(p.colscale, nv + i);
-  }
-  if (p.snake_alpha) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { t.al[i] = vec_at<T>(p.snake_alpha, nv + i); t.ial[i] = 1.0f / (t.al[i] + 1e-9f); }
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void gemm_tail_res(const GemmArgs& p, int m, int n0, int zo, int zi, float (&r)[4]) {
-  typedef Vec4<T> V;
-  if (p.res) V::unpack(*(const typename V::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
-}
-
-template <typename T>
-__device__ __forceinline__ void gemm_tail_apply(const GemmArgs& p, int m, int n0, float (&y)[4], const TailCols& t, const float (&res)[4], T* C,
-                                                T* C2) {
-  typedef Vec4<T> V;
-  if (p.acc_scale != 1.0f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] *= p.acc_scale;
-  }
-  if (p.bias) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] += t.bias[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i]);
-  if (p.div != 0.0f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
-  }
-  if (p.act == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
-  } else if (p.act == 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(gelu_erf_f(y[i]));
-  }
-  if (p.colscale) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] * t.cs[i]);
-  }
-  if (p.res) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + res[i]);
-  }
-  if (p.store_main) *(typename V::raw*)(C + (long)m * p.ldc + n0) = V::pack(y);
-  if (p.snake_alpha) {
-    float sn4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float al = t.al[i];
-      const float sn = sinf(al * y[i]);
-      sn4[i] = Num<T>::rnd(y[i] + t.ial[i] * (sn * sn));      // the reciprocal is a per-column constant: same value, divided once per tile
-    }
-    *(typename V::raw*)(C2 + (long)m * p.ldc + n0) = V::pack(sn4);
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void gemm_tail(const GemmArgs& p, int m, int n0, float (&y)[4], int zo, int zi, T* C, T* C2) {
-  TailCols t;
-  float res[4] = {0.f, 0.f, 0.f, 0.f};
-  gemm_tail_cols<T>(p, n0, zo, zi, t);
-  gemm_tail_res<T>(p, m, n0, zo, zi, res);
-  gemm_tail_apply<T>(p, m, n0, y, t, res, C, C2);
-}
-
-template <typename T>
-__device__ __forceinline__ void swiglu_tail(const GemmArgs& p, int m, int j0, const f32x4& a4, const f32x4& b4, T* C) {
-  float o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = Num<T>::rnd(a4[i]);
-    const float bb = Num<T>::rnd(b4[i]);
-    o[i] = Num<T>::rnd(Num<T>::rnd(Num<T>::is_bf16 ? silu_fast(a) : silu_f(a)) * bb);
-  }
-  *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + j0) = Vec4<T>::pack(o);
-}
-
-// ---- epilogue shared by the tile kernels, 32 output rows per pass through LDS (the staging buffers are free after
-// the last barrier): the owning waves write their accumulators as 16-byte chunks into a [32][BN/4] fp32 slab
-// (chunk ^= row, conflict spreading; `put(pass, slab)`), then all threads re-read it row-wise so that consecutive lanes
-// cover consecutive columns of one row: global stores are whole row segments and the fused tail is emitted once.
-// position of 16-byte chunk `chunk` of slab row `ml` (conflict spreading): XOR for power-of-two rows, rotation otherwise
-template <int CPR>
-__device__ __forceinline__ int slab_pos(int ml, int chunk) {
-  if constexpr ((CPR & (CPR - 1)) == 0) return ml * CPR + (chunk ^ ml);
-  else return ml * CPR + (chunk + ml) % CPR;
-}
-
-// cycle accounting of the diagnostic build (s_memtime sums per wave; compiled out unless PROF)
-struct EpiProf { unsigned long long t_bar1 = 0, t_put = 0, t_bar2 = 0, t_rw = 0; };
-#define EPI_STAMP(var) do { if constexpr (PROF) { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); prof->var += n__ - last__; last__ = n__; } } while (0)
-
-// NTAIL: 0 = every tail, 1 = the row-layout tails only (generic / SwiGLU): instantiations launched without split-K and without the fused QKV tail
-// do not carry those branches (and their registers) at all - see gemm_pp_kernel's TAIL
-template <typename T, bool SWIGLU, int BM, int BN, int NT, bool DRAIN, bool PROF = false, int NTAIL = 0, typename PutFn>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, int tid, int tile_m, int tile_n, int tiles_m, int zo, int zi,
-                                              long c_z, int split, PutFn put, EpiProf* prof = nullptr) {
-  // tid / tile coordinates behind an opaque asm: the epilogue's per-thread address arithmetic is then computed HERE, after the K loop, instead
-  // of being hoisted above it and kept in registers through it (the 256 x 192 split3 instantiation spilled 30 VGPRs for that)
-  asm volatile("" : "+v"(tid));
-  asm volatile("" : "+s"(tile_m), "+s"(tile_n));
-  unsigned long long last__ = 0;
-  if constexpr (PROF) last__ = __builtin_amdgcn_s_memtime();
-  T* C = (T*)p.C + c_z;
-  T* C2 = (T*)p.C2 + c_z;
-  constexpr int CPR = BN / 4;               // chunks per slab row
-  constexpr int NPASS = BM / 32;
-  // DRAIN: the slab reuses the staging buffers, so every LDS-DMA of the main loop must have landed first
-  if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0);
-  TailCols tcols;   // per-column tail operands of this thread's chunk (generic branch), read in the first pass
-  // generic branch: every thread keeps ONE 4-column chunk for the whole tile (threads beyond the last full row of chunks idle), so the
-  // per-column operands are read once per tile; rows advance by NT / CPR per step.  The residual rows of pass p + 1 are requested
-  // while pass p is processed: requested inside their own pass, the first load of every pass sat exposed behind the pass's two
-  // barriers (the DAC's 1-tap conv + residual launches: four ~2 us round trips per 128-row tile of a kernel with three K steps).
-  constexpr int RPS = NT / CPR, NTA = RPS * CPR, ITER = (32 + RPS - 1) / RPS;
-  const int g_chunk = tid % CPR, g_r0 = tid / CPR;
-  const int g_n0 = tile_n * BN + g_chunk * 4;
-  const bool g_col_ok = tid < NTA && g_n0 < p.N;
-  const bool generic = NTAIL == 1 ? !SWIGLU : (!(p.ksplit > 1) && !SWIGLU && !p.qkv_mode);
-  float rs_next[ITER][4];
-#pragma unroll
-  for (int k = 0; k < ITER; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rs_next[k][i] = 0.f;
-  auto fetch_res = [&](int pass_) __attribute__((always_inline)) {
-    const int mrow = tile_m * BM + pass_ * 32;
-#pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-      const int ml = g_r0 + k * RPS;
-      if (g_col_ok && ml < 32 && mrow + ml < p.M) gemm_tail_res<T>(p, mrow + ml, g_n0, zo, zi, rs_next[k]);
-    }
-  };
-  if (generic && p.res) fetch_res(0);
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-    // raw barriers + lgkmcnt only: __syncthreads() would also wait (vmcnt) for the previous pass's global stores
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    EPI_STAMP(t_bar1);
-    put(pass, slab);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    EPI_STAMP(t_put);
-    __builtin_amdgcn_s_barrier();
-    EPI_STAMP(t_bar2);
-    const int mrow0 = tile_m * BM + pass * 32;
-    if (NTAIL == 0 && p.ksplit > 1) {
-      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
-      float* ws = (float*)p.ws + ((long)split * tiles_m * BM + mrow0) * (long)p.Npad + (long)tile_n * BN;
-#pragma unroll
-      for (int idx = tid; idx < 32 * CPR; idx += NT) {
-        const int ml = idx / CPR, chunk = idx % CPR;
-        if (tile_n * BN + chunk * 4 < p.Npad)
-          *(f32x4*)(ws + (long)ml * p.Npad + chunk * 4) = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
-      }
-    } else if constexpr (SWIGLU) {
-      // packed rows [16 x w1 | 16 x w3] per 32: chunk pair (b*8 + q, b*8 + 4 + q) -> output columns b*16 + 4q ..
-#pragma unroll
-      for (int idx = tid; idx < 32 * (CPR / 2); idx += NT) {
-        const int ml = idx / (CPR / 2), pc = idx % (CPR / 2);
-        const int b = pc >> 2, q = pc & 3;
-        const int m = mrow0 + ml;
-        const int j0 = tile_n * (BN / 2) + b * 16 + q * 4;
-        if (m >= p.M || j0 >= (p.N >> 1)) continue;
-        const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, b * 8 + q) * 4);
-        const f32x4 b4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, b * 8 + 4 + q) * 4);
-        swiglu_tail<T>(p, m, j0, a4, b4, C);
-      }
-    } else if (NTAIL == 0 && p.qkv_mode) {
-      const int D = p.qkv_D;
-      const int sec = (tile_n * BN) / D;           // the whole tile lies in one of q | k | v | gate (D % BN == 0)
-      if (sec == 2) {
-        // V section: transposed store, 8 consecutive tokens of one d per thread
-#pragma unroll
-        for (int idx = tid; idx < BN * 4; idx += NT) {
-          const int col = idx % BN, sg = idx / BN;
-          const int m = mrow0 + 8 * sg;
-          if (m >= p.M) continue;
-          float v8[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int rw = 8 * sg + r;
-            v8[r] = Num<T>::rnd(slab[slab_pos<CPR>(rw, col >> 2) * 4 + (col & 3)]);
-          }
-          const int hd = tile_n * BN + col - 2 * D;        // h * 128 + d
-          const int b = m / p.qkv_S, sidx = m - b * p.qkv_S;
-          T* dst = (T*)p.vt + (long)b * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
-          if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
-            *(typename Vec4<T>::raw*)dst = Vec4<T>::pack(v8);
-            *(typename Vec4<T>::raw*)(dst + 4) = Vec4<T>::pack(v8 + 4);
-          } else {
-            for (int r = 0; r < 8 && m + r < p.M; ++r) {
-              const int bb = (m + r) / p.qkv_S, ss = (m + r) - bb * p.qkv_S;
-              ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(v8[r]);
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int idx = tid; idx < 32 * CPR; idx += NT) {
-          const int ml = idx / CPR, chunk = idx % CPR;
-          const int m = mrow0 + ml;
-          const int n0 = tile_n * BN + chunk * 4;
-          const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
-          float y[4] = {Num<T>::rnd(a4[0]), Num<T>::rnd(a4[1]), Num<T>::rnd(a4[2]), Num<T>::rnd(a4[3])};
-          if (sec < 2) {
-            // 32 consecutive lanes hold the 128 columns of one (token, head): half-wave reduction of the squares
-            float ss = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            const float rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int nd = n0 - sec * D;                   // h * 128 + d
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              y[i] = Num<T>::rnd(__fmul_rn(__fmul_rn(y[i], rs), vec_at<T>(p.qk_w, (long)sec * D + nd + i)));
-            if ((nd >> 7) < p.rope_heads) {
-              const int pos = p.pos0 + m % p.qkv_S;
-              const float2* rp = (const float2*)p.rope + (long)pos * 64 + ((nd & 127) >> 1);
-#pragma unroll
-              for (int pr = 0; pr < 2; ++pr) {
-                const float2 cs = rp[pr];
-                const float a = y[2 * pr], bq = y[2 * pr + 1];
-                y[2 * pr] = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(bq, cs.y));
-                y[2 * pr + 1] = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(bq, cs.x));
-              }
-            }
-          }
-          if (sec == 3 && p.qkv_gate_act) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(sigmoid_fast(y[i]));
-          }
-          if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
-        }
-      }
-    } else {
-      const int chunk = g_chunk, r0 = g_r0, n0 = g_n0;
-      const bool col_ok = g_col_ok;
-      if (pass == 0 && col_ok) gemm_tail_cols<T>(p, n0, zo, zi, tcols);
-      float rs[ITER][4];
-#pragma unroll
-      for (int k = 0; k < ITER; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rs[k][i] = rs_next[k][i];
-      if (p.res && pass + 1 < NPASS) fetch_res(pass + 1);
-#pragma unroll
-      for (int k = 0; k < ITER; ++k) {
-        const int ml = r0 + k * RPS, m = mrow0 + ml;
-        if (col_ok && ml < 32 && m < p.M) {
-          const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml, chunk) * 4);
-          float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-          gemm_tail_apply<T>(p, m, n0, y, tcols, rs[k], C, C2);
-        }
-      }
-    }
-    EPI_STAMP(t_rw);
-  }
-}
-
-// SPLIT3 (fp32 only): every fp32 operand x is split in registers into bf16 hi = bf16(x), lo = bf16(x - hi) and the
-// product is evaluated as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (relative error ~2^-16 per
-// product, ~1e-5 on sums): 16/3 times the fp32-MFMA rate.  Used for the Fish S1-DAC decoder whose 1e-4 waveform
-// tolerance leaves three orders of magnitude of head room; the parity-mode DiT keeps the exact fp32 MFMA.
-template <typename T, bool SWIGLU, typename CF, bool SPLIT3, int NTAIL = 0>
-__global__ void __launch_bounds__(CF::NT, CF::WAVES_PER_SIMD) gemm_nt_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KE = KBYTES / (int)sizeof(T);
-  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN, PPW = CF::PPW, STAGES = CF::STAGES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // column tiles cover N (the packed SwiGLU rows: Npad); a tile that lies wholly in the row padding of W is not launched
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = ((SWIGLU ? p.Npad : p.N) + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {  // bijective XCD remap: workgroups that share an XCD (bid % 8) get a contiguous run of tiles
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
-  const int z = blockIdx.y, zo = z / p.nbi, zi = z - zo * p.nbi;
-  const long a_z = zo * p.a_bo + zi * p.a_bi, w_z = zo * p.w_bo + zi * p.w_bi, c_z = zo * p.c_bo + zi * p.c_bi;
-
-  // ---- K range of this workgroup (split-K over blockIdx.z)
-  const int kb_per_tap = p.K / KE;
-  const int nk_total = kb_per_tap * p.taps;
-  const int ks = p.ksplit > 1 ? p.ksplit : 1;
-  const int split = blockIdx.z;
-  const int it0 = (int)((long)nk_total * split / ks), it1 = (int)((long)nk_total * (split + 1) / ks);
-  const int nk = it1 - it0;
-
-  // ---- DMA sources: wave w owns pieces w*PPW .. w*PPW+PPW-1 of the combined [A rows | W rows] stage image
-  const char* src[PPW];
-  bool is_a[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int piece = wid * PPW + i;
-    const int r = piece * 8 + (lane >> 3);            // row inside the stage image
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);    // source-side swizzle (BM is a multiple of 16)
-    is_a[i] = piece * 8 < BM;
-    if (is_a[i]) {
-      int gm = tile_m * BM + r;
-      gm = gm < p.M ? gm : p.M - 1;
-      src[i] = (const char*)p.A + ((long)(gm + p.tap_base) * p.lda + a_z) * (long)sizeof(T) + chunk * 16;
-    } else {
-      int gn = tile_n * BN + (r - BM);
-      gn = gn < p.Npad ? gn : p.Npad - 1;
-      src[i] = (const char*)p.W + ((long)gn * p.ldw + w_z) * (long)sizeof(T) + chunk * 16;
-    }
-  }
-  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * (long)sizeof(T);  // extra A step at a tap boundary
-  int kb = it0 % kb_per_tap;
-  long a_off = (long)(it0 / kb_per_tap) * p.tap_shift * p.lda * (long)sizeof(T) + (long)kb * KBYTES;
-  long w_off = (long)it0 * KBYTES;
-
-  // DMA of one stage: sources are resolved first (next_src), the PPW pieces are then issued one at a time between the
-  // MFMAs of the current tile (issue_piece): a burst of 8 LDS-DMA instructions blocks the wave for ~500-1800 cycles.
-  const char* nsrc[PPW];
-  char* ndst = nullptr;
-  auto next_src = [&](int slot) {
-    ndst = smem + slot * CF::STAGE_BYTES + wid * (PPW * 1024);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) nsrc[i] = src[i] + (is_a[i] ? a_off : w_off);
-    a_off += KBYTES; w_off += KBYTES;
-    if (++kb == kb_per_tap) { kb = 0; a_off += a_tap_bytes; }
-  };
-  auto stage = [&](int slot) {
-    next_src(slot);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(nsrc[i], ndst + i * 1024);
-  };
-
-  // ---- fragment read addresses
-  const int wm = wid / CF::NWN, wn = wid % CF::NWN;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (lane >> 1) & 7;   // == ((row >> 1) & 7): all row bases are multiples of 16
-  const int a_row0 = (wm * CF::WM + fr) * KBYTES;
-  const int w_row0 = (BM + wn * CF::WN + fr) * KBYTES;
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // ---- pipeline: STAGES-1 tiles in flight
-  int issued = 0;
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (issued < nk) { stage(s); ++issued; }
-
-  constexpr int NMF = (Num<T>::is_bf16 ? 4 : 16) * TN * TM;   // MFMAs per K step and wave
-  // the K loop exists twice in the SPLIT3 kernels: with W split in registers, and with W pre-split by the host side into [32 hi | 32 lo]
-  // bf16 per 32-float block (GemmArgs.w_presplit: static weights; the split of a weight fragment is 24 VALU instructions that every
-  // wave of every row tile repeated - the 128x96 tile spent 96 VALU per 9 MFMAs on it)
-  auto kloop = [&](auto wpre_) __attribute__((always_inline)) {
-  constexpr bool WPRE = decltype(wpre_)::value;
-  for (int it = 0; it < nk; ++it) {
-    // tile `it` must have landed: allow (tiles still in flight - 1) * PPW younger DMA pieces to stay outstanding
-    const int younger = issued - it - 1;
-    if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * PPW>();
-    else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPW>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile `it` are in LDS; everyone finished reading tile it-1
-    const bool more = issued < nk;   // wave-uniform
-    if (more) { next_src((it + STAGES - 1) % STAGES); ++issued; }
-
-    const char* sa = smem + (it % STAGES) * CF::STAGE_BYTES;
-    int mf = 0, piece = 0;
-    // after every MFMA: issue the next DMA piece when due, then pin the order (sched_barrier) so that the pieces stay
-    // spread over the tile instead of being hoisted into one burst
-    auto after_mfma = [&]() {
-      ++mf;
-      // all pieces go out in the first 1/DMA_SPREAD_DEN of the tile (more than one per call where a wave has more
-      // pieces than MFMA groups, e.g. the 128x96 split3 tile: 7 pieces, 6 groups)
-#pragma unroll
-      for (int due = 0; due < PPW; ++due) {
-        if (piece < PPW && mf * PPW * DMA_SPREAD_DEN >= (piece + 1) * NMF) {
-          if (more) glds16(nsrc[piece], ndst + piece * 1024);
-          ++piece;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    if constexpr (Num<T>::is_bf16) {
-      bf16x8 wf[2][TN], af[2][TM];
-      auto load = [&](int kk, int b) {
-        const int c = ((2 * kk + fh) ^ sw) << 4;
-#pragma unroll
-        for (int t = 0; t < TN; ++t) wf[b][t] = *(const bf16x8*)(sa + w_row0 + t * 32 * KBYTES + c);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) af[b][t] = *(const bf16x8*)(sa + a_row0 + t * 32 * KBYTES + c);
-      };
-      load(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) load(kk + 1, (kk + 1) & 1);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tn], af[kk & 1][tm], acc[tn][tm], 0, 0, 0);
-            after_mfma();
-          }
-      }
-    } else if constexpr (SPLIT3) {
-      // 32 floats per row and K step = two bf16 MFMA k-steps of 16; lane (fr, fh) needs floats 16kk + 8fh .. +7
-      auto split = [&](const char* rowp, int kk, bf16x8& hi, bf16x8& lo) {
-        const f32x4 x0 = *(const f32x4*)(rowp + (((4 * kk + 2 * fh) ^ sw) << 4));
-        const f32x4 x1 = *(const f32x4*)(rowp + (((4 * kk + 2 * fh + 1) ^ sw) << 4));
-        f32x8 x;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = x0[i]; x[4 + i] = x1[i]; }
-        const hbf16x8 h = __builtin_convertvector(x, hbf16x8);
-        const f32x8 hf = __builtin_convertvector(h, f32x8);
-        const hbf16x8 l = __builtin_convertvector(x - hf, hbf16x8);
-        hi = __builtin_bit_cast(bf16x8, h);
-        lo = __builtin_bit_cast(bf16x8, l);
-      };
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 whi[TN], wlo[TN], ahi[TM], alo[TM];
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-          if constexpr (WPRE) {      // the block holds bf16 hi[0..31] | lo[0..31]: chunks 0-3 | 4-7 of 16 bytes, same swizzle
-            const char* rowp = sa + w_row0 + t * 32 * KBYTES;
-            whi[t] = *(const bf16x8*)(rowp + (((2 * kk + fh) ^ sw) << 4));
-            wlo[t] = *(const bf16x8*)(rowp + (((4 + 2 * kk + fh) ^ sw) << 4));
-          } else split(sa + w_row0 + t * 32 * KBYTES, kk, whi[t], wlo[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TM; ++t) split(sa + a_row0 + t * 32 * KBYTES, kk, ahi[t], alo[t]);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[tn], ahi[tm], acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[tn], alo[tm], acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[tn], ahi[tm], acc[tn][tm], 0, 0, 0);
-            mf += 7; after_mfma();   // 3 bf16 MFMAs stand for 8 fp32 ones in the DMA-piece schedule (NMF counts fp32 MFMAs)
-          }
-      }
-    } else {
-      f32x4 wf[2][TN], af[2][TM];
-      auto load = [&](int cc, int b) {
-        const int c = (cc ^ sw) << 4;
-#pragma unroll
-        for (int t = 0; t < TN; ++t) wf[b][t] = *(const f32x4*)(sa + w_row0 + t * 32 * KBYTES + c);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) af[b][t] = *(const f32x4*)(sa + a_row0 + t * 32 * KBYTES + c);
-      };
-      load(0, 0);
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        if (cc < 7) load(cc + 1, (cc + 1) & 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-              acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fh ? wf[cc & 1][tn][2 * s + 1] : wf[cc & 1][tn][2 * s],
-                                                                 fh ? af[cc & 1][tm][2 * s + 1] : af[cc & 1][tm][2 * s],
-                                                                 acc[tn][tm], 0, 0, 0);
-              after_mfma();
-            }
-      }
-    }
-  }
-  };
-  if constexpr (SPLIT3) { if (p.w_presplit) kloop(std::true_type{}); else kloop(std::false_type{}); }
-  else kloop(std::false_type{});
-
-  // ---- epilogue (gemm_epilogue): this wave's accumulators of one 32-row pass go into the LDS slab
-  const int fr_ = fr, fh_ = fh;
-  gemm_epilogue<T, SWIGLU, BM, BN, CF::NT, true, false, NTAIL>(p, (float*)smem, tid, tile_m, tile_n, tiles_m, zo, zi, c_z, split, [&](int pass, float* slab) {
-    constexpr int CPR = BN / 4;
-    if (wm == pass / TM) {
-      const int tm_sel = pass % TM;
-      auto put = [&](const f32x16& a, int tn) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int chunk = wn * (CF::WN / 4) + tn * 8 + 2 * g + fh_;
-          f32x4 v;
-          v[0] = a[4 * g]; v[1] = a[4 * g + 1]; v[2] = a[4 * g + 2]; v[3] = a[4 * g + 3];
-          *(f32x4*)(slab + slab_pos<CPR>(fr_, chunk) * 4) = v;
-        }
-      };
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        // static register indices only (a runtime-indexed accumulator array would live in scratch)
-        if (tm_sel == 0) put(acc[tn][0], tn);
-        if constexpr (TM > 1) { if (tm_sel == 1) put(acc[tn][1], tn); }
-        if constexpr (TM > 2) { if (tm_sel == 2) put(acc[tn][2], tn); }
-        if constexpr (TM > 3) { if (tm_sel == 3) put(acc[tn][3], tn); }
-      }
-    }
-  });
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// gemm_pp_kernel: bf16, 256x256 output tile, K-tile 64, 8 waves (4 M x 2 N, 64 x 128 outputs each) on
-// v_mfma_f32_16x16x32_bf16, written for one workgroup per CU (160 KiB LDS, <= 256 VGPRs).
-//
-// The two waves of every SIMD (wave w and w + 4) run the same program HALF A PHASE APART ("ping-pong"): while one is
-// inside a cluster of 16 MFMAs, its partner issues the LDS fragment reads and the LDS-DMA of its next phase, and they
-// swap roles at every workgroup barrier, so the matrix pipe of the SIMD always has one wave feeding it
-// (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md §5 "256² 8-phase").
-//
-// A K-tile is 4 phases; phase q computes one 32 x 64 quadrant of the wave's outputs over K = 64:
-//     q0 (m-half 0, n-half 0)   q1 (0, 1)   q2 (1, 1)   q3 (1, 0)
-// and reads only the fragments it does not hold yet: q0 A(m-half 0) + W(n-half 0), q1 W(n-half 1), q2 A(m-half 1).
-// The LDS image of a K-tile is cut the same way into four 16 KiB UNITS, staged one per phase in the order they are
-// first read:  j0 = A rows of m-half 0 (all four wave rows),  j1 = W rows of n-half 0 (both wave columns),
-// j2 = W n-half 1,  j3 = A m-half 1.  Unit u = 4t + j is issued in phase u - LEAD (2 LDS-DMA instructions per wave)
-// into a ring of two K-tiles.  Ordering, with G0 = waves 0-3 and G1 = waves 4-7 one barrier behind:
-//   RAW  every wave waits for its own DMA of the units first read in phase r with a counted vmcnt in the load part of
-//        phase r - 1 (at most 2 (LEAD - 2) younger DMAs stay in flight), then passes the barrier that ends that
-//        part; both groups have done so before either reads (G0 reads two barriers, G1 one barrier later);
-//   WAR  unit u overwrites unit u - 8, last read in phase u - 8 - {0,1,1,1}[j]; those reads are retired by the
-//        lgkmcnt(0) in front of that phase's first barrier, so restaging two phases later is safe: LEAD <= 6.
-// Never vmcnt(0) in the loop: the look-ahead units of the last phases re-stage the final K-tile into dead ring slots.
-//
-// The kernel is PERSISTENT: gridDim.x workgroups (one per CU) walk the tile list with stride gridDim.x, and the unit
-// stream simply continues from the last K-tile of one output tile into the first K-tile of the next, so the LDS-DMA of
-// the next tile is in flight while the accumulators of the current one go through the epilogue.
-//
-// Epilogue (pp_epilogue): no workgroup barriers.  Tails that work per output column or per (row, head) run on the
-// accumulator layout in registers (SwiGLU pairs, q/k head RMSNorm + RoPE: a wave owns 128 columns = one head); then
-// every wave turns its own 16-row x 64-column pieces through a PRIVATE 4 KiB LDS area (behind the ring) into rows of
-// 8 consecutive columns per lane, applies the row-layout tail (bias / activation / column scale / residual / Snake) and
-// stores 16 bytes per lane: each store instruction writes eight whole 128-byte lines.  The V section of the fused QKV
-// projection takes the same route with rows and columns exchanged (Vᵀ is written 8 tokens per lane).
-#ifndef PP_LEAD
-#define PP_LEAD 5
-#endif
-#ifndef PP_GN
-#define PP_GN 4
-#endif
-#ifndef PP_RES_AHEAD
-#define PP_RES_AHEAD 1
-#endif
-template <int V> struct IC { static constexpr int value = V; };
-
-__device__ __forceinline__ uint4 pack8_bf16(const float* y) {
-  uint4 r;
-  r.x = pack_bf16x2(y[0], y[1]); r.y = pack_bf16x2(y[2], y[3]); r.z = pack_bf16x2(y[4], y[5]); r.w = pack_bf16x2(y[6], y[7]);
-  return r;
-}
-__device__ __forceinline__ void unpack8_bf16(uint4 r, float* f) {
-  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
-}
-
-// gemm_tail on 8 consecutive bf16 columns (same operation order and rounding points); GELU / Snake / the second output
-// belong to the fp32 DAC path and are rejected at launch for this kernel
-__device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, float (&y)[8], int zo, int zi, bf16_t* C) {
-  typedef bf16_t T;
-  if (p.acc_scale != 1.0f) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] *= p.acc_scale;
-  }
-  const int nv = p.vec_mod ? n0 % p.vec_mod : n0;
-  if (p.bias) {
-    float b[8];
-    unpack8_bf16(*(const uint4*)((const T*)p.bias + zo * p.bias_bo + zi * p.bias_bi + nv), b);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] += b[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i]);
-  if (p.div != 0.0f) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] / p.div);
-  }
-  if (p.act == 1) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(silu_f(y[i]));
-  }
-  if (p.colscale) {
-    float c[8];
-    unpack8_bf16(*(const uint4*)((const T*)p.colscale + nv), c);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] * c[i]);
-  }
-  if (p.res) {
-    float r[8];
-    unpack8_bf16(*(const uint4*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)m * p.ldres + n0), r);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = Num<T>::rnd(y[i] + r[i]);
-  }
-  *(uint4*)(C + (long)m * p.ldc + n0) = pack8_bf16(y);
-}
-
-// DIAG (timing experiments only): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 4 = no epilogue
-// (1-4 give wrong results); 5 = correct results + per-wave cycle sums (s_memtime) written to p.ws: {total, K loops,
-// epilogue, tiles} x 8 waves per workgroup; 6 = correct results + per-wave, per-phase cycle sums {load part, wait at
-// barrier 1, MFMA part, wait at barrier 2} x 4 phases; 7 = the epilogue without its global stores (wrong results)
-//
-// FP8: A and W are OCP e4m3 bytes (K-tile = 128 elements = the same 128-byte rows, so staging, ring and phases are unchanged);
-// a phase is 8 v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 FLOPs per cycle) on fragments of 32
-// consecutive K bytes per lane, and the accumulators are multiplied by a_scale[m] * w_scale[n] before the bf16 tails.
-// TAIL: which epilogues an instantiation carries.  One kernel with every tail (split-K slabs, fused QKV, the row-layout tails) needs the
-// union of their registers: the all-tails build of round 2 had 71 VGPR + 108 SGPR spills (272 bytes of scratch per lane) around its tile
-// hand-over while the SwiGLU-only instantiation had 2 and the epilogue-less timing build none.  TAIL_ROWS = the row-layout tails only (plain
-// store, column scale + residual: wo / w2, and the generic bias / activation form), TAIL_QKV = the fused QKV(G) tail only, TAIL_ALL = everything
-// (split-K and the diagnostic builds).  The launcher picks the instantiation from the arguments.
-enum { TAIL_ALL = 0, TAIL_ROWS = 1, TAIL_QKV = 2, TAIL_FAST = 3 };      // TAIL_FAST: y = T(acc) [* colscale] [+ residual] only (QKV-less plain store, wo, w2)
-template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false, int TAIL = TAIL_ALL>
-__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
-  typedef bf16_t T;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = 256, BN = 256, KE = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, UNIT = 16384, KTILE = 4 * UNIT;
-  static_assert(LEAD >= 2 && LEAD <= 6, "see the WAR/RAW rules above");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Npad + BN - 1) / BN;
-  const int ntiles = tiles_m * tiles_n;
-  const int G = gridDim.x;                       // <= ntiles
-  // virtual block id v -> tile: bijective XCD remap (workgroups that share an XCD walk one contiguous run of tiles;
-  // G is a multiple of 8 or equals ntiles, so v % 8 == blockIdx.x % 8 for every tile of this workgroup)
-  // The linear index b runs through strips of PP_GN tile columns, row by row inside a strip: the 32 tiles an XCD works
-  // on at one time form an 8 x 4 block (8 A panels + 4 W panels through its L2 instead of 32 + 1).
-  auto tile_of = [&](int v, int& tm, int& tn) __attribute__((always_inline)) {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
-    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GN = p.pp_gn > 0 ? p.pp_gn : PP_GN;
-    const int strip = b / (GN * tiles_m), rem = b - strip * (GN * tiles_m);
-    const int w = tiles_n - strip * GN < GN ? tiles_n - strip * GN : GN;
-    tm = rem / w; tn = strip * GN + (rem - tm * w);
-  };
-  const int z = blockIdx.y, zo = z / p.nbi, zi = z - zo * p.nbi;
-  const long a_z = zo * p.a_bo + zi * p.a_bi, w_z = zo * p.w_bo + zi * p.w_bi, c_z = zo * p.c_bo + zi * p.c_bi;
-
-  const int kb_per_tap = p.K / KE;
-  const int nk_total = kb_per_tap * p.taps;
-  const int ks = p.ksplit > 1 ? p.ksplit : 1;
-  const int split = blockIdx.z;
-  const int it0 = (int)((long)nk_total * split / ks), it1 = (int)((long)nk_total * (split + 1) / ks);
-  const int nk = it1 - it0;
-
-  // ---- DMA sources: per unit type j, wave w copies rows 16w .. 16w + 15 of the unit as two 8-row pieces.  The per-lane
-  // part of the address is a 32-bit byte offset that only changes with the output tile; everything that moves inside a
-  // tile (K position, tap) and the batch offset are wave-uniform and live in the 64-bit scalar cursors.
-  unsigned voff[4][2];
-  const unsigned lda_b = (unsigned)(p.lda * ES), ldw_b = (unsigned)(p.ldw * ES);      // row pitches in bytes
-  auto set_stage_tile = [&](int v) __attribute__((always_inline)) {
-    int tm, tn;
-    tile_of(v, tm, tn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ur = (wid * 2 + i) * 8 + (lane >> 3);       // row inside the unit
-        const int chunk = (lane & 7) ^ ((ur >> 1) & 7);        // source-side swizzle
-        if (j == 0 || j == 3) {                                // A: unit row = wave row (ur >> 5) x 32 rows of this m-half
-          int gm = tm * BM + (ur >> 5) * 64 + (j == 3 ? 32 : 0) + (ur & 31);
-          gm = gm < p.M ? gm : p.M - 1;
-          voff[j][i] = (unsigned)gm * lda_b + (unsigned)(chunk * 16);     // 32-bit on purpose (launch_sw refuses operands whose row offsets need more)
-        } else {                                               // W: unit row = wave column (ur >> 6) x 64 rows of this n-half
-          int gn = tn * BN + (ur >> 6) * 128 + (j == 2 ? 64 : 0) + (ur & 63);
-          gn = gn < p.Npad ? gn : p.Npad - 1;
-          voff[j][i] = (unsigned)gn * ldw_b + (unsigned)(chunk * 16);
-        }
-      }
-  };
-  // staging cursors (wave-uniform): A units j0, j3 of one K-tile share a_cur, W units j1, j2 share w_cur.  After the
-  // last K-tile of an output tile the stream moves on to the next tile of this workgroup; after the last tile the
-  // cursors stop, so the look-ahead units of the final phases re-stage the last K-tile into ring slots nobody reads
-  // again: every phase issues exactly two DMAs per wave and the counted vmcnt holds to the end.
-  const long a_tap_bytes = ((long)p.tap_shift * p.lda - (long)p.K) * ES;
-  const int kb0 = it0 % kb_per_tap;
-  const char* const a_start = (const char*)p.A + ((long)p.tap_base * p.lda + a_z + (long)(it0 / kb_per_tap) * p.tap_shift * p.lda) * ES + (long)kb0 * KBYTES;
-  const char* const w_start = (const char*)p.W + w_z * ES + (long)it0 * KBYTES;
-  const char* a_cur = a_start;
-  const char* w_cur = w_start;
-  int kb = kb0, kt_staged = 0, v_stage = blockIdx.x;
-  bool in_loop = false;
-  set_stage_tile(v_stage);
-  // SWITCH = false: the caller knows that this unit is not the last one of an output tile (the steady K loop), so the
-  // tile hand-over (new per-lane offsets, cursor reset) is compiled out of the hot path
-  auto issue_unit = [&](auto jc, int buf, auto swc) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
-    constexpr bool SWITCH = decltype(swc)::value != 0;
-    char* dst = smem + buf * KTILE + j * UNIT + wid * 2048;
-    const char* base = (j == 0 || j == 3) ? a_cur : w_cur;
-    if (DIAG != 1 || !in_loop) {
-      glds16(base + voff[j][0], dst);
-      glds16(base + voff[j][1], dst + 1024);
-    }
-    if constexpr (!SWITCH) {
-      if (j == 2) w_cur += KBYTES;
-      if (j == 3) {
-        ++kt_staged;
-        a_cur += KBYTES;
-        if (++kb == kb_per_tap) { kb = 0; a_cur += a_tap_bytes; }
-      }
-    } else {
-      if (j == 2 && kt_staged + 1 < nk) w_cur += KBYTES;
-      if (j == 3) {
-        if (kt_staged + 1 < nk) {
-          ++kt_staged;
-          a_cur += KBYTES;
-          if (++kb == kb_per_tap) { kb = 0; a_cur += a_tap_bytes; }
-        } else if (v_stage + G < ntiles) {       // wave-uniform: on to the first K-tile of this workgroup's next tile
-          v_stage += G;
-          set_stage_tile(v_stage);
-          kt_staged = 0; kb = kb0; a_cur = a_start; w_cur = w_start;
-        }
-      }
-    }
-  };
-
-  // ---- fragment read addresses: lane (r = lane & 15, g = lane >> 4) reads row r of a 16-row fragment, k-chunk g (+ 4)
-  const int wm = wid >> 1, wn = wid & 1;
-  const int fr = lane & 15, fg = lane >> 4;
-  // bf16: swizzled 16-byte chunk fg of k-half 0, k-half 1 is c0 ^ 64.  fp8: the lane's 32 K bytes are chunks 2 fg, 2 fg + 1
-  const int c0 = (((FP8 ? 2 * fg : fg) ^ (fr >> 1)) & 7) << 4;
-  constexpr int C1X = FP8 ? 16 : 64;
-  const int a_rd0 = (wm * 32 + fr) * KBYTES + c0, a_rd1 = a_rd0 ^ C1X;   // + unit j0 / j3, + 16 i rows
-  const int w_rd0 = (wn * 64 + fr) * KBYTES + c0, w_rd1 = w_rd0 ^ C1X;   // + unit j1 / j2, + 16 jn rows
-
-  f32x4 acc[4][8];                 // [m fragment][n fragment]: lane holds C[m = 16 i + fr][n = 16 jn + 4 fg + r]
-  bf16x8 af[2][2], wf[2][4][2];    // A (i, k-half) of the current m-half; W (n-half, jn, k-half); fp8: (.., 16-byte half of the 32 K bytes)
-
-  // ---- prologue: the first LEAD units; units 0 and 1 must have landed everywhere before phase 0 reads them
-#pragma unroll
-  for (int u = 0; u < LEAD; ++u) {
-    if ((u & 3) == 0) issue_unit(IC<0>{}, (u >> 2) & 1, IC<1>{});
-    if ((u & 3) == 1) issue_unit(IC<1>{}, (u >> 2) & 1, IC<1>{});
-    if ((u & 3) == 2) issue_unit(IC<2>{}, (u >> 2) & 1, IC<1>{});
-    if ((u & 3) == 3) issue_unit(IC<3>{}, (u >> 2) & 1, IC<1>{});
-  }
-  wait_vmcnt<2 * (LEAD - 2)>();
-  __builtin_amdgcn_s_barrier();
-  in_loop = true;
-  if constexpr (DIAG == 2) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { af[i][0] = af[i][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { wf[0][i][0] = wf[0][i][1] = wf[1][i][0] = wf[1][i][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; }
-  }
-
-  // t = K-tile counter of this workgroup over ALL its output tiles (ring parity)
-  unsigned long long ph_acc[4][4] = {};   // DIAG 6: [phase][load part, wait at barrier 1 (+ lgkmcnt), MFMA part, wait at barrier 2]
-  auto phase = [&](auto qc, int t, auto swc) __attribute__((always_inline)) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;
-    const char* sb = smem + (t & 1) * KTILE;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-    if constexpr (DIAG == 6) s0 = __builtin_amdgcn_s_memtime();
-    // ---- load part: fragments first read in this phase
-    if constexpr (DIAG != 2 && (q == 0 || q == 1)) {
-      const char* wp = sb + (q == 0 ? 1 : 2) * UNIT;
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) {
-        wf[nh][jn][0] = *(const bf16x8*)(wp + w_rd0 + jn * 16 * KBYTES);
-        wf[nh][jn][1] = *(const bf16x8*)(wp + w_rd1 + jn * 16 * KBYTES);
-      }
-    }
-    if constexpr (q == 0) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DIAG != 2 && (q == 0 || q == 2)) {
-      const char* ap = sb + (q == 0 ? 0 : 3) * UNIT;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i][0] = *(const bf16x8*)(ap + a_rd0 + i * 16 * KBYTES);
-        af[i][1] = *(const bf16x8*)(ap + a_rd1 + i * 16 * KBYTES);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- stage the unit LEAD phases ahead
-    {
-      constexpr int jj = (q + LEAD) & 3, dt = (q + LEAD) >> 2;
-      issue_unit(IC<jj>{}, (t + dt) & 1, swc);
-    }
-    // ---- the units first read in the next phase have landed (this wave's part of them)
-    if constexpr (q != 2) wait_vmcnt<2 * (LEAD - 2)>();
-    if constexpr (DIAG == 6) s1 = __builtin_amdgcn_s_memtime();
-    // the fragments are retired BEFORE the barrier (the wave would only wait at the barrier anyway; measured +3-4 % over
-    // waiting behind it), and no s_setprio flips around the MFMA cluster (measured +3 %: the partner wave is in its load
-    // part and barely competes for the vector issue port; the sched_barriers keep the cluster between the two barriers)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (DIAG == 6) s2 = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DIAG == 3) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[i][0]), "v"(af[i][1]));
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) asm volatile("" :: "v"(wf[nh][jn][0]), "v"(wf[nh][jn][1]));
-    } else
-    if constexpr (FP8) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, af[i][0]), __builtin_bit_cast(i32x4, af[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-          const i32x8 w8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wf[nh][jn][0]), __builtin_bit_cast(i32x4, wf[nh][jn][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-          // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0 in every byte (the row scales are applied in the epilogue)
-          acc[2 * mh + i][4 * nh + jn] =
-              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[2 * mh + i][4 * nh + jn], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        }
-      }
-    } else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-          acc[2 * mh + i][4 * nh + jn] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][jn][kk], af[i][kk], acc[2 * mh + i][4 * nh + jn], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DIAG == 6) s3 = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();
-    if constexpr (DIAG == 6) {
-      s4 = __builtin_amdgcn_s_memtime();
-      ph_acc[q][0] += s1 - s0; ph_acc[q][1] += s2 - s1; ph_acc[q][2] += s3 - s2; ph_acc[q][3] += s4 - s3;
-    }
-  };
-
-  // ---- epilogue pieces
-  float* const my = (float*)(smem + 2 * KTILE) + wid * 1024;     // this wave's private 16 x 64 fp32 transposition area
-  T* const C = (T*)p.C + c_z;
-  // Epilogue-local copies of the lane coordinates, re-derived behind an opaque asm at every tile's epilogue: hipcc otherwise hoists the
-  // epilogue's per-lane address arithmetic (LDS transposition addresses, row offsets) out of the tile loop and keeps it in registers ACROSS the
-  // K loop, which already sits at 256 - the all-tails build carried 71 VGPR spills (scratch stores / loads around every tile hand-over, in the
-  // same in-order vmcnt stream as the LDS-DMA units) for it.
-  int lane_e = lane, fr_e = fr, fg_e = fg;
-  // 16 rows x 64 columns held as v[c][r] = X[row fr][col 16 c + 4 fg + r]  ->  fn(row, c8, y[8]) with
-  // y = X[row][8 c8 .. 8 c8 + 7], row = 8 it + lane / 8, c8 = lane % 8.  Same-wave LDS traffic is executed in order.
-  auto rows = [&](const f32x4 (&v)[4], auto&& fn) __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = v[c];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = it * 8 + (lane_e >> 3), c8 = lane_e & 7;
-      const f32x4 a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
-      const f32x4 b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
-      float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      fn(row, c8, y);
-    }
-  };
-
-  int tcount = 0;
-  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, n_tiles = 0, rt_start = 0;
-  if constexpr (DIAG == 5) { t_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
-#pragma unroll 1
-  for (int v = blockIdx.x; v < ntiles; v += G) {
-    int tile_m, tile_n;
-    tile_of(v, tile_m, tile_n);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    unsigned long long t_l0 = 0;
-    if constexpr (DIAG == 5) t_l0 = __builtin_amdgcn_s_memtime();
-    if (wid >= 4) __builtin_amdgcn_s_barrier();   // stagger: G1 runs one barrier behind G0 through the K loop
-    // steady part: while K-tile t < nk - 2 is computed, the units staged (K-tiles t + 1, t + 2) all belong to this
-    // output tile; the last two K-tiles run the general copy whose look-ahead crosses into the next output tile
-    int t = 0;
-#pragma unroll 1
-    for (; t + 2 < nk; ++t, ++tcount) {
-      phase(IC<0>{}, tcount, IC<0>{}); phase(IC<1>{}, tcount, IC<0>{}); phase(IC<2>{}, tcount, IC<0>{}); phase(IC<3>{}, tcount, IC<0>{});
-    }
-#pragma unroll 1
-    for (; t < nk; ++t, ++tcount) {
-      phase(IC<0>{}, tcount, IC<1>{}); phase(IC<1>{}, tcount, IC<1>{}); phase(IC<2>{}, tcount, IC<1>{}); phase(IC<3>{}, tcount, IC<1>{});
-    }
-    if (wid < 4) __builtin_amdgcn_s_barrier();    // level again: both groups run their epilogues side by side
-    if constexpr (DIAG == 5) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_loop += n - t_l0; t_l0 = n; ++n_tiles; }
-
-    lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    fr_e = lane_e & 15; fg_e = lane_e >> 4;
-    // the tile coordinates too: everything the epilogue derives from them (64-bit row offsets of C / the residual, ...) is computed HERE,
-    // behind the K loop, instead of at the top of the iteration and carried through it
-    asm volatile("" : "+s"(tile_m), "+s"(tile_n));
-    const int m_base = tile_m * BM + wm * 64;      // + 16 i + row
-    const int n_base = tile_n * BN + wn * 128;     // + 64 h + 8 c8 (W-row index of the accumulator columns)
-    if constexpr (FP8) {
-      // dequantise in the accumulator layout: lane_e holds C[m_base + 16 i + fr_e][n_base + 16 jn + 4 fg_e + r]
-      float sa[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const int m = m_base + 16 * i + fr_e; sa[i] = p.a_scale ? p.a_scale[m < p.M ? m : p.M - 1] : p.a_scale_const; }
-#pragma unroll
-      for (int jn = 0; jn < 8; ++jn) {
-        const int n0 = n_base + 16 * jn + 4 * fg_e;
-        const f32x4 sw = *(const f32x4*)(p.w_scale + (n0 + 3 < p.Npad ? n0 : p.Npad - 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][jn][r] *= sa[i] * sw[r];
-      }
-    }
-    if constexpr (DIAG == 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
-    } else if (TAIL == TAIL_ALL && p.ksplit > 1) {
-      // raw fp32 partial sums to the split-K workspace [split][Mpad][Npad]; the reduce kernel applies the tail
-      float* ws = (float*)p.ws + (long)split * tiles_m * BM * (long)p.Npad;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x4 v4[4] = {acc[i][4 * h], acc[i][4 * h + 1], acc[i][4 * h + 2], acc[i][4 * h + 3]};
-          rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
-            const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
-            if (n0 < p.Npad) {
-              float* d = ws + (long)m * p.Npad + n0;
-              *(f32x4*)d = f32x4{y[0], y[1], y[2], y[3]};
-              *(f32x4*)(d + 4) = f32x4{y[4], y[5], y[6], y[7]};
-            }
-          });
-        }
-    } else if constexpr (SWIGLU) {
-      // W rows come in 32-row groups [16 x w1 | 16 x w3]: fragments jn = 2k, 2k + 1 of one lane_e are the (a, b) pairs
-      // of output columns 16 k + 4 fg_e + r (model.py:307); 64 output columns per wave
-      const int j_base = tile_n * (BN / 2) + wn * 64;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = Num<T>::rnd(acc[i][2 * k][r]), bb = Num<T>::rnd(acc[i][2 * k + 1][r]);
-            v4[k][r] = Num<T>::rnd(Num<T>::rnd(silu_fast(a)) * bb);
-          }
-        rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
-          const int m = m_base + 16 * i + row, j0 = j_base + 8 * c8;
-          if (m < p.M && j0 < (p.N >> 1)) {
-            if constexpr (FP8) {
-              if (p.c8) {      // static activation scale: e4m3 bytes for the w2 GEMM (the values are bf16-rounded already)
-                float z[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = __builtin_amdgcn_fmed3f(y[e] * p.c8_inv, -448.0f, 448.0f);
-                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], 0, false);
-                lo = __builtin_amdgcn_cvt_pk_fp8_f32(z[2], z[3], lo, true);
-                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(z[4], z[5], 0, false);
-                hi = __builtin_amdgcn_cvt_pk_fp8_f32(z[6], z[7], hi, true);
-                *(int2*)((uint8_t*)p.c8 + (long)m * p.c8_ld + j0) = int2{lo, hi};
-                return;
-              }
-            }
-            *(uint4*)(C + (long)m * p.ldc + j0) = pack8_bf16(y);
-          }
-        });
-      }
-    } else if ((TAIL == TAIL_ALL || TAIL == TAIL_QKV) && (TAIL == TAIL_QKV || p.qkv_mode)) {
-      const int D = p.qkv_D;
-      const int sec = (tile_n * BN) / D;            // the whole tile lies in one of q | k | v | gate (D % 256 == 0)
-      if (sec == 2) {
-        // V: Vt[b][h * 128 + d][token]; this wave holds 64 tokens x the 128 d of one head.  Per 16 d (fragment jn) the
-        // four token fragments go through the private area as [d][token] and leave as 8 tokens per lane_e.
-        const int hd_base = n_base - 2 * D;
-#pragma unroll
-        for (int jn = 0; jn < 8; ++jn) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + 16 * i + fr_e] = Num<T>::rnd(acc[i][jn][r]);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int dl = it * 8 + (lane_e >> 3), t8 = lane_e & 7;
-            const f32x4 a = *(const f32x4*)(my + dl * 64 + 8 * t8);
-            const f32x4 b = *(const f32x4*)(my + dl * 64 + 8 * t8 + 4);
-            const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            const int m = tile_m * BM + wm * 64 + 8 * t8;
-            const int hd = hd_base + 16 * jn + dl;
-            if (m < p.M) {
-              const int bq = m / p.qkv_S, sidx = m - bq * p.qkv_S;
-              T* dst = (T*)p.vt + (long)bq * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
-              if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
-                *(uint4*)dst = pack8_bf16(y);
-              } else {
-                for (int e = 0; e < 8 && m + e < p.M; ++e) {
-                  const int bb = (m + e) / p.qkv_S, ss = (m + e) - bb * p.qkv_S;
-                  ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(y[e]);
-                }
-              }
-            }
-          }
-        }
-      } else {
-        // q | k | gate sections.  The rope values (cos, sin) and norm weights of a 16-token x 64-column piece are requested
-        // as ONE batch (four 16-byte + four 8-byte loads) in front of its arithmetic: one exposed L2 round trip per piece
-        // instead of one per 16-column fragment (in-situ: the loads issued one at a time cost 91 us of a 543 us launch at
-        // M = 15360).  Larger batches (a whole row, or a row ahead) pushed the kernel over its 256 registers and spilled
-        // the accumulators.
-        const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg_e + r)
-        const bool do_rope = sec < 2 && (nd0 >> 7) < p.rope_heads;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 yv[8];
-#pragma unroll
-          for (int jn = 0; jn < 8; ++jn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
-          if (sec == 3 && p.qkv_gate_act) {      // the attention epilogue's sigmoid, moved here (same operations on the same bf16 values)
-#pragma unroll
-            for (int jn = 0; jn < 8; ++jn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(sigmoid_fast(yv[jn][r]));
-          }
-          float rs = 0.f;
-          const float4* rp = nullptr;
-          if (sec < 2) {
-            // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
-            // lane_e, the other 96 in lanes fr_e + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
-            float ss = 0.f;
-#pragma unroll
-            for (int jn = 0; jn < 8; ++jn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) ss += yv[jn][r] * yv[jn][r];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int m = m_base + 16 * i + fr_e;
-            const int pos = p.pos0 + m % p.qkv_S;
-            rp = (const float4*)((const float2*)p.rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
-          }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (sec < 2) {
-              float4 cs[4];
-              uint2 w4p[4];
-              const T* wp = (const T*)p.qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg_e;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
-              if (do_rope) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h + j)];
-              }
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int jn = 4 * h + j;
-                float w4[4];
-                Vec4<T>::unpack(w4p[j], w4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
-                if (do_rope) {
-                  const float4 c4 = cs[j];                       // two (cos, sin) pairs
-                  const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
-                  yv[jn][0] = __fsub_rn(__fmul_rn(a0, c4.x), __fmul_rn(b0, c4.y));
-                  yv[jn][1] = __fadd_rn(__fmul_rn(a0, c4.y), __fmul_rn(b0, c4.x));
-                  yv[jn][2] = __fsub_rn(__fmul_rn(a1, c4.z), __fmul_rn(b1, c4.w));
-                  yv[jn][3] = __fadd_rn(__fmul_rn(a1, c4.w), __fmul_rn(b1, c4.z));
-                }
-              }
-            }
-            const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
-            rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
-              const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
-              if (m < p.M && n0 < p.N) *(uint4*)(C + (long)m * p.ldc + n0) = pack8_bf16(y);
-            });
-          }
-        }
-      }
-    } else if (TAIL == TAIL_QKV) {
-      // (this instantiation is only launched with qkv_mode set)
-    } else if (TAIL == TAIL_FAST || (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7)) {
-      // fast path of the big EchoDiT linears: y = T(acc) [* colscale] [+ residual].  Fully unrolled (static accumulator
-      // reads), addresses hoisted: one 64-bit per-lane_e offset per tile, everything else wave-uniform; the residual rows of
-      // a piece are requested before its LDS round trip; interior tiles skip the per-element bounds tests.
-      const int row0 = lane_e >> 3, c8 = lane_e & 7;
-      const bool full = m_base + 64 <= p.M && n_base + 128 <= p.N;          // wave-uniform
-      const long off0 = (long)(m_base + row0) * p.ldc + n_base + 8 * c8;
-      const long roff0 = (long)(m_base + row0) * p.ldres + n_base + 8 * c8;
-      const T* const resp = p.res ? (const T*)p.res + zo * p.res_bo + zi * p.res_bi : nullptr;
-      float cs[2][8];
-      if (p.colscale) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int n0 = n_base + 64 * h + 8 * c8;
-          unpack8_bf16(n0 < p.N ? *(const uint4*)((const T*)p.colscale + n0) : uint4{0, 0, 0, 0}, cs[h]);
-        }
-      }
-      // the residual chunks of piece pc + 1 are requested before piece pc goes through LDS and is stored: a load issued
-      // behind a store would wait for that store's round trip too (one in-order vmcnt), once per piece
-      // RES_AHEAD pieces of residual are in flight (measured round 3 with 1 / 3 / 7: no difference, wo 446 / 432-445 / 437-449 us at M = 46080)
-      constexpr int RES_AHEAD = PP_RES_AHEAD, RQN = RES_AHEAD + 1;
-      uint4 rq[RQN][2];
-      auto load_res = [&](int pc, uint4 (&r)[2]) __attribute__((always_inline)) {
-        const int i = pc >> 1, h = pc & 1;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          r[it] = uint4{0, 0, 0, 0};
-          const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
-          if (resp && (full || (m < p.M && n0 < p.N))) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
-        }
-      };
-#pragma unroll
-      for (int a = 0; a < RES_AHEAD && a < 8; ++a) load_res(a, rq[a % RQN]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int pc = 2 * i + h;
-          if (pc + RES_AHEAD < 8) load_res(pc + RES_AHEAD, rq[(pc + RES_AHEAD) % RQN]);
-          const uint4 (&rr)[2] = rq[pc % RQN];
-          if constexpr (DIAG != 9) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = acc[i][4 * h + c];
-          }
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int row = it * 8 + row0;
-            f32x4 a, b;
-            if constexpr (DIAG == 9) { a = acc[i][4 * h + 2 * it]; b = acc[i][4 * h + 2 * it + 1]; }      // timing experiment: no LDS round trip (wrong layout)
-            else {
-              a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
-              b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
-            }
-            float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e]);
-            if (p.colscale) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] * cs[h][e]);
-            }
-            if (resp) {
-              float r[8];
-              unpack8_bf16(rr[it], r);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] + r[e]);
-            }
-            const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
-            if constexpr (DIAG == 8) {           // timing experiment: the fast-path epilogue without its global stores
-              const uint4 pk = pack8_bf16(y);
-              asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
-            } else
-            if (full || (m < p.M && n0 < p.N)) *(uint4*)(C + off0 + (long)(16 * i + 8 * it) * p.ldc + 64 * h) = pack8_bf16(y);
-          }
-        }
-    } else if constexpr (TAIL != TAIL_FAST) {
-      // the tail is emitted once (runtime loop over the 8 pieces); the accumulators of piece 2 i + h are picked by
-      // static register reads pinned with an empty asm (merged stores would turn `acc` into a scratch array)
-#pragma unroll 1
-      for (int piece = 0; piece < 8; ++piece) {
-        f32x4 v4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if (piece == 2 * i + h) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) { v4[c] = acc[i][4 * h + c]; asm volatile("" : "+v"(v4[c])); }
-            }
-        const int i_ = piece >> 1, h_ = piece & 1;
-        rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
-          const int m = m_base + 16 * i_ + row, n0 = n_base + 64 * h_ + 8 * c8;
-          if constexpr (DIAG == 7) {          // timing experiment: the whole epilogue but the global stores
-            asm volatile("" :: "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
-          } else {
-            if (m < p.M && n0 < p.N) gemm_tail8(p, m, n0, y, zo, zi, C);
-          }
-        });
-      }
-    }
-    if constexpr (DIAG == 5) t_epi += __builtin_amdgcn_s_memtime() - t_l0;
-  }
-  if constexpr (DIAG == 6) {
-    if (lane == 0 && p.ws) {
-      unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 16;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[q * 4 + e] = ph_acc[q][e];
-    }
-  }
-  if constexpr (DIAG == 5) {
-    if (lane == 0 && p.ws) {
-      unsigned long long* o = (unsigned long long*)p.ws + ((long)blockIdx.x * 8 + wid) * 8;
-      o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_loop; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memrealtime() - rt_start;   // o[3]: 100 MHz ticks
-      o[4] = 0; o[5] = 0; o[6] = n_tiles; o[7] = 0;
-    }
-  }
-  wait_vmcnt<0>();   // the re-staged look-ahead units must not land after the workgroup has released its LDS
-}
-
-// sums the split-K partial slabs in split order (deterministic) and applies the fused tail
-template <typename T, bool SWIGLU>
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs p, int Mpad) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const float* ws = (const float*)p.ws;
-  const long slab = (long)Mpad * p.Npad;
-  if constexpr (SWIGLU) {
-    const int cpr = p.Npad / 8;                      // output chunks per row
-    const int m = (int)(idx / cpr), pc = (int)(idx % cpr);
-    const int blk = pc >> 2, q = pc & 3;             // 32-row packed block, 4-column group
-    const int j0 = blk * 16 + q * 4;
-    if (m >= p.M || j0 >= (p.N >> 1)) return;
-    f32x4 a4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0};
-    for (int s = 0; s < p.ksplit; ++s) {
-      const float* r = ws + s * slab + (long)m * p.Npad + blk * 32 + q * 4;
-      const f32x4 x = *(const f32x4*)r, y = *(const f32x4*)(r + 16);
-      a4 += x; b4 += y;
-    }
-    swiglu_tail<T>(p, m, j0, a4, b4, (T*)p.C);
-  } else {
-    const int cpr = p.Npad / 4;
-    const int m = (int)(idx / cpr), n0 = (int)(idx % cpr) * 4;
-    if (m >= p.M || n0 >= p.N) return;
-    f32x4 a4 = {0, 0, 0, 0};
-    for (int s = 0; s < p.ksplit; ++s) a4 += *(const f32x4*)(ws + s * slab + (long)m * p.Npad + n0);
-    float y[4] = {a4[0], a4[1], a4[2], a4[3]};
-    gemm_tail<T>(p, m, n0, y, 0, 0, (T*)p.C, (T*)p.C2);
-  }
-}
-
-template <typename T, bool SW, typename CF, bool SPLIT3, int NTAIL>
-hipError_t launch_cfg_tail(const GemmArgs& g, hipStream_t st);
-
-template <typename T, bool SW, typename CF, bool SPLIT3 = false>
-hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
-  static const bool split = getenv("ECHO_NT_TAILS") ? atoi(getenv("ECHO_NT_TAILS")) != 0 : true;      // 0: the all-tails instantiation everywhere (A/B aid)
-  if (split && g.ksplit <= 1 && !g.qkv_mode) return launch_cfg_tail<T, SW, CF, SPLIT3, 1>(g, st);
-  return launch_cfg_tail<T, SW, CF, SPLIT3, 0>(g, st);
-}
-
-template <typename T, bool SW, typename CF, bool SPLIT3, int NTAIL>
-hipError_t launch_cfg_tail(const GemmArgs& g, hipStream_t st) {
-  static std::atomic<unsigned long long> prepared{0};
-  auto kern = gemm_nt_kernel<T, SW, CF, SPLIT3, NTAIL>;
-  if (hipError_t e = ensure_dyn_lds((const void*)kern, CF::SMEM, prepared); e != hipSuccess) return e;
-  const int tiles_m = (g.M + CF::BM - 1) / CF::BM, tiles_n = ((SW ? g.Npad : g.N) + CF::BN - 1) / CF::BN;
-  const int ks = g.ksplit > 1 ? g.ksplit : 1;
-  dim3 grid(tiles_m * tiles_n, g.nbatch, ks);
-  hipLaunchKernelGGL(kern, grid, dim3(CF::NT), CF::SMEM, st, g);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || ks == 1) return e;
-  const int Mpad = tiles_m * CF::BM;
-  const long items = (long)g.M * (SW ? g.Npad / 8 : g.Npad / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<T, SW>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g, Mpad);
-  return hipGetLastError();
-}
-
-int pp_num_cus() {
-  static std::atomic<int> cached[64];          // per device ordinal; 0 = not queried yet
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::atomic<int>& slot = cached[dev & 63];
-  int n = slot.load(std::memory_order_relaxed);
-  if (!n) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-    n &= ~7;                                   // a multiple of the 8 XCDs (tile_of)
-    if (const char* e = getenv("ECHO_PP_GRID")) { const int v = atoi(e); if (v >= 8) n = v & ~7; }
-    slot.store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
-
-template <bool SW, int DIAG, int LEAD, bool FP8, int TAIL>
-hipError_t launch_pp_tail(const GemmArgs& g_in, hipStream_t st);
-
-template <bool SW, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false>
-hipError_t launch_pp(const GemmArgs& g, hipStream_t st) {
-  // the production builds (DIAG 0, default LEAD) come in tail-specialised instantiations (see gemm_pp_kernel); ECHO_PP_TAILS=0 forces the
-  // all-tails build (A/B aid)
-  if constexpr (DIAG == 0 && LEAD == PP_LEAD && !SW) {
-    static const bool split = getenv("ECHO_PP_TAILS") ? atoi(getenv("ECHO_PP_TAILS")) != 0 : true;
-    if (split && g.ksplit <= 1) {
-      if (g.qkv_mode) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_QKV>(g, st);
-      if (g.acc_scale == 1.0f && !g.bias && g.div == 0.0f && g.act == 0 && !g.vec_mod) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_FAST>(g, st);
-      return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_ROWS>(g, st);
-    }
-  }
-  return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_ALL>(g, st);
-}
-
-template <bool SW, int DIAG, int LEAD, bool FP8, int TAIL>
-hipError_t launch_pp_tail(const GemmArgs& g_in, hipStream_t st) {
-  GemmArgs g = g_in;
-  static const int env_gn = getenv("ECHO_PP_GN") ? atoi(getenv("ECHO_PP_GN")) : 0;
-  if (g.pp_gn <= 0 && env_gn > 0) g.pp_gn = env_gn;
-  static std::atomic<unsigned long long> prepared{0};
-  auto kern = gemm_pp_kernel<SW, DIAG, LEAD, FP8, TAIL>;
-  constexpr int SMEM = 2 * 4 * 16384 + 32 * 256 * 4;      // ring of two K-tiles + epilogue slab = 160 KiB
-  if (hipError_t e = ensure_dyn_lds((const void*)kern, SMEM, prepared); e != hipSuccess) return e;
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.Npad + 255) / 256;
-  const int ntiles = tiles_m * tiles_n;
-  const int ks = g.ksplit > 1 ? g.ksplit : 1;
-  const int ncu = pp_num_cus();
-  dim3 grid(ntiles < ncu ? ntiles : ncu, g.nbatch, ks);   // persistent: one workgroup per CU walks the tile list
-  hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, st, g);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || ks == 1) return e;
-  const int Mpad = tiles_m * 256;
-  const long items = (long)g.M * (SW ? g.Npad / 8 : g.Npad / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, SW>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g, Mpad);
-  return hipGetLastError();
-}
-
-typedef TileCfg<128, 128, 2, 2, 2> Cfg0;   // 4 waves, 64 KiB: two workgroups per CU
-typedef TileCfg<128, 128, 2, 2, 4> Cfg1;   // 4 waves, 128 KiB, 3 tiles in flight: latency-bound small grids
-typedef TileCfg<256, 256, 2, 4, 2> Cfg2;   // 8 waves (128x64 each), 128 KiB: lowest L2 traffic per FLOP
-typedef TileCfg<256, 128, 4, 2, 3> Cfg3;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
-typedef TileCfg<128, 256, 2, 4, 3> Cfg4;   // 8 waves (64x64 each), 144 KiB, 2 tiles in flight
-typedef TileCfg<128, 192, 2, 2, 2> Cfg6;   // 4 waves (64x96 each), 80 KiB: N = 192 / 384 without padding waste (DAC 192- and 384-channel convs)
-typedef TileCfg<128, 96, 4, 1, 2> Cfg7;    // 4 waves (32x96 each), 56 KiB: N = 96 (DAC 96-channel convs)
-typedef TileCfg<256, 192, 4, 2, 2> Cfg8;   // 8 waves (64x96 each), 112 KiB: less L2->LDS traffic per output for the long-M convs
-typedef TileCfg<384, 96, 6, 1, 2> Cfg9;    // 6 waves (64x96 each), 120 KiB: N = 96, the weight tile amortised over 384 rows
-
-template <typename T, bool SW>
-hipError_t launch_sw(const GemmArgs& g, hipStream_t st) {
-  if constexpr (!Num<T>::is_bf16) {
-    if (g.cfg == 5 || g.cfg >= 100) return hipErrorInvalidValue;   // the ping-pong kernel (and its diagnostic builds) is bf16 only
-    if (g.split3) {
-      switch (g.cfg) {
-        case 6: return launch_cfg<T, SW, Cfg6, true>(g, st);
-        case 7: return launch_cfg<T, SW, Cfg7, true>(g, st);
-        case 8: return launch_cfg<T, SW, Cfg8, true>(g, st);
-        case 9: return launch_cfg<T, SW, Cfg9, true>(g, st);
-        case 1: return launch_cfg<T, SW, Cfg1, true>(g, st);
-        case 2: return launch_cfg<T, SW, Cfg2, true>(g, st);
-        case 3: return launch_cfg<T, SW, Cfg3, true>(g, st);
-        case 4: return launch_cfg<T, SW, Cfg4, true>(g, st);
-        default: return launch_cfg<T, SW, Cfg0, true>(g, st);
-      }
-    }
-  }
-  if (g.cfg == 5 || g.cfg >= 100) {
-    // 16-byte row stores / loads: every row pitch and column count the epilogue touches must be a multiple of 8
-    if ((g.N & 7) || (g.ldc & 7) || (g.res && (g.ldres & 7)) || (g.swiglu && (g.N & 15)) || (g.vec_mod & 7) || g.act == 2 ||
-        g.snake_alpha || g.C2 || !g.store_main ||
-        (g.qkv_mode && ((g.qkv_D & 255) || (g.vt_ld & 7))))
-      return hipErrorInvalidValue;
-    // the per-lane part of a DMA source address is a 32-bit byte offset (row * pitch + chunk): refuse operands it cannot span
-    const long es = g.fp8 ? 1 : 2;
-    if ((long)(g.M - 1) * g.lda * es + 128 >= (1L << 32) || (long)(g.Npad - 1) * g.ldw * es + 128 >= (1L << 32)) return hipErrorInvalidValue;
-  }
-  if (g.fp8 && g.cfg != 5 && g.cfg != 104 && g.cfg != 105 && g.cfg != 108) return hipErrorInvalidValue;   // fp8 operands exist for the ping-pong kernel (and three of its diagnostic builds) only
-  if (g.c8 && !(g.fp8 && SW && g.ksplit <= 1 && (g.c8_ld & 7) == 0 && g.c8_inv > 0.0f)) return hipErrorInvalidValue;   // e4m3 output: SwiGLU tail of the fp8 kernel only
-  if (g.cfg == 5) {
-    if constexpr (Num<T>::is_bf16) {
-      if (g.fp8) {
-        if ((!g.a_scale && !(g.a_scale_const > 0.0f)) || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
-        return launch_pp<SW, 0, PP_LEAD, true>(g, st);
-      }
-      return launch_pp<SW>(g, st);
-    } else return hipErrorInvalidValue;   // the ping-pong kernel is bf16 only
-  }
-  if (g.cfg >= 100) {   // timing experiments (tools/bench_gemm.py --diag): wrong results by construction
-    if constexpr (Num<T>::is_bf16 && !SW) {
-      if (g.fp8) {      // tools/prof_fp8.py: no epilogue (wrong results) / cycle sums per wave / per-phase cycle sums
-        if ((!g.a_scale && !(g.a_scale_const > 0.0f)) || !g.w_scale || (g.K & 127) || (g.lda & 15) || (g.ldw & 15) || (g.Npad & 3)) return hipErrorInvalidValue;
-        if (g.cfg == 104) return launch_pp<false, 4, PP_LEAD, true>(g, st);
-        if (g.cfg == 105) return launch_pp<false, 5, PP_LEAD, true>(g, st);
-        if (g.cfg == 108) return launch_pp<false, 6, PP_LEAD, true>(g, st);
-        return hipErrorInvalidValue;
-      }
-      if (g.cfg == 101) return launch_pp<false, 1>(g, st);
-      if (g.cfg == 102) return launch_pp<false, 2>(g, st);
-      if (g.cfg == 103) return launch_pp<false, 3>(g, st);
-      if (g.cfg == 104) return launch_pp<false, 4>(g, st);
-      if (g.cfg == 105) return launch_pp<false, 5>(g, st);
-      if (g.cfg == 108) return launch_pp<false, 6>(g, st);
-      if (g.cfg == 109) return launch_pp<false, 7>(g, st);
-      if (g.cfg == 110) return launch_pp<false, 8>(g, st);      // fast-path epilogue without global stores
-      if (g.cfg == 111) return launch_pp<false, 9>(g, st);      // fast-path epilogue without the LDS round trip
-      if (g.cfg == 106) return launch_pp<false, 0, 6>(g, st);
-      if (g.cfg == 107) return launch_pp<false, 0, 4>(g, st);
-    }
-    return hipErrorInvalidValue;
-  }
-  if (g.cfg >= 6 && g.qkv_mode) return hipErrorInvalidValue;   // the fused QKV tail needs tiles that divide a section (BN | D)
-  switch (g.cfg) {
-    case 1: return launch_cfg<T, SW, Cfg1>(g, st);
-    case 2: return launch_cfg<T, SW, Cfg2>(g, st);
-    case 3: return launch_cfg<T, SW, Cfg3>(g, st);
-    case 4: return launch_cfg<T, SW, Cfg4>(g, st);
-    case 6: return launch_cfg<T, SW, Cfg6>(g, st);
-    case 7: return launch_cfg<T, SW, Cfg7>(g, st);
-    case 8: return launch_cfg<T, SW, Cfg8>(g, st);
-    case 9: return launch_cfg<T, SW, Cfg9>(g, st);
-    default: return launch_cfg<T, SW, Cfg0>(g, st);
-  }
-}
-
-}  // namespace
-
 int gemm_tile_m(int cfg) { return cfg == 9 ? 384 : cfg == 2 || cfg == 3 || cfg == 5 || cfg == 8 || cfg >= 100 ? 256 : 128; }
 int gemm_num_cfgs() { return 10; }
 
-template <typename T>
-hipError_t launch_gemm_nt(const GemmArgs& g, hipStream_t st) {
-  constexpr int KE = KBYTES / (int)sizeof(T);
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % KE != 0 || g.Npad % 128 != 0 || g.Npad < g.N || (g.N & 3) ||
-      g.taps < 1 || g.nbatch < 1 || g.nbi < 1 || (g.lda % (16 / (int)sizeof(T))) || (g.ldw % (16 / (int)sizeof(T))) ||
-      (g.ldc & 3) || g.cfg < 0 || (g.cfg >= gemm_num_cfgs() && (g.cfg < 101 || g.cfg > 111)))
-    return hipErrorInvalidValue;
-  if (g.qkv_mode && (g.ksplit > 1 || g.swiglu || g.nbatch != 1 || g.qkv_D % 256 || !g.vt || !g.qk_w || !g.rope || g.qkv_S < 1))
-    return hipErrorInvalidValue;
-  if (g.ksplit > 1) {
-    if (g.nbatch != 1 || !g.ws || g.ksplit > (g.K / KE) * g.taps) return hipErrorInvalidValue;
-    const long need = (long)g.ksplit * ((g.M + gemm_tile_m(g.cfg) - 1) / gemm_tile_m(g.cfg)) * gemm_tile_m(g.cfg) * g.Npad * 4;
-    if (g.ws_bytes < need) return hipErrorInvalidValue;
-  }
-  return g.swiglu ? launch_sw<T, true>(g, st) : launch_sw<T, false>(g, st);
-}
 template hipError_t launch_gemm_nt<bf16_t>(const GemmArgs&, hipStream_t);
-template hipError_t launch_gemm_nt<float>(const GemmArgs&, hipStream_t);
+
 
 // In-place reformat of an fp32 weight matrix [rows][ld] (ld % 32 == 0) for GemmArgs.w_presplit: every aligned block of 32 floats
 // becomes 32 bf16 hi = bf16(x) followed by 32 bf16 lo = bf16(x - hi) - the values the SPLIT3 kernels compute in registers.
