@@ -469,12 +469,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + 16 * i + fr_e] = Num<T>::rnd(acc[i][jn][r]);
-#pragma unroll
+            for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + ((16 * i + fr_e) ^ (16 * fg_e))] = Num<T>::rnd(acc[i][jn][r]);     // token ^ 16 (d >> 2): the four
+#pragma unroll                                                                                                               // fg groups of a ds_write_b32 hit 4 bank groups, not 1
           for (int it = 0; it < 2; ++it) {
             const int dl = it * 8 + (lane_e >> 3), t8 = lane_e & 7;
-            const f32x4 a = *(const f32x4*)(my + dl * 64 + 8 * t8);
-            const f32x4 b = *(const f32x4*)(my + dl * 64 + 8 * t8 + 4);
+            const int tsw = (8 * t8) ^ (16 * (dl >> 2));
+            const f32x4 a = *(const f32x4*)(my + dl * 64 + tsw);
+            const f32x4 b = *(const f32x4*)(my + dl * 64 + tsw + 4);
             const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             const int m = tile_m * BM + wm * 64 + 8 * t8;
             const int hd = hd_base + 16 * jn + dl;
