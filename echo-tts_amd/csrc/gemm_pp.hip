@@ -60,6 +60,27 @@ __device__ __forceinline__ void unpack8_bf16(uint4 r, float* f) {
   f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 
+// global stores the compiler's wait-count pass does not see (edge tiles of the branch-free tails, see gemm_pp_kernel's fast tail): the hardware
+// vmcnt then runs ahead of the compiler's count, so its counted waits wait for at least what they meant to.  s_nop: the store-data hazard slot.
+__device__ __forceinline__ void hidden_store16(void* dst, uint4 pk) {
+  const i32x4 pv = {(int)pk.x, (int)pk.y, (int)pk.z, (int)pk.w};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" :: "v"(dst), "v"(pv) : "memory");
+}
+__device__ __forceinline__ void hidden_store2(void* dst, bf16_t v) {
+  const int iv = v;
+  asm volatile("global_store_short %0, %1, off\n\ts_nop 0" :: "v"(dst), "v"(iv) : "memory");
+}
+
+// Start of one epilogue FORM (a branch-free copy of a tail for one case): the lane coordinates are re-derived behind an asm that is different
+// in every form, so that nothing computed from them is "the same instruction" in two forms - hipcc otherwise hoists the loads (and the unpacking)
+// that two forms share above the branch that picks the form and carries them, spilled, through it.
+template <int FORM> __device__ __forceinline__ void form_lane(int& lane_e, int& fr_e, int& fg_e) {
+  asm volatile("; epilogue form %1" : "+v"(lane_e) : "n"(FORM));
+  fr_e = lane_e & 15; fg_e = lane_e >> 4;
+}
+
+template <int FORM> __device__ __forceinline__ void form_touch(f32x4& v) { asm volatile("; form %1" : "+v"(v) : "n"(FORM)); }      // the same for an accumulator block
+
 // gemm_tail on 8 consecutive bf16 columns (same operation order and rounding points); GELU / Snake / the second output
 // belong to the fp32 DAC path and are rejected at launch for this kernel
 __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, float (&y)[8], int zo, int zi, bf16_t* C) {
@@ -113,7 +134,8 @@ __device__ __forceinline__ void gemm_tail8(const GemmArgs& p, int m, int n0, flo
 // hand-over while the SwiGLU-only instantiation had 2 and the epilogue-less timing build none.  TAIL_ROWS = the row-layout tails only (plain
 // store, column scale + residual: wo / w2, and the generic bias / activation form), TAIL_QKV = the fused QKV(G) tail only, TAIL_ALL = everything
 // (split-K and the diagnostic builds).  The launcher picks the instantiation from the arguments.
-enum { TAIL_ALL = 0, TAIL_ROWS = 1, TAIL_QKV = 2, TAIL_FAST = 3 };      // TAIL_FAST: y = T(acc) [* colscale] [+ residual] only (QKV-less plain store, wo, w2)
+typedef const __attribute__((address_space(4))) GemmArgs* kargs_t;      // the kernel's argument block in the kernarg segment
+enum { TAIL_ALL = 0, TAIL_ROWS = 1, TAIL_QKV = 2, TAIL_FAST = 3, TAIL_FASTR = 4 };      // TAIL_FAST: y = T(acc) only (plain store); TAIL_FASTR: y = T(T(T(acc) * colscale) + residual) (wo, w2)
 template <bool SWIGLU, int DIAG = 0, int LEAD = PP_LEAD, bool FP8 = false, int TAIL = TAIL_ALL>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   typedef bf16_t T;
@@ -155,12 +177,17 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   auto set_stage_tile = [&](int v) __attribute__((always_inline)) {
     int tm, tn;
     tile_of(v, tm, tn);
+    // the lane coordinate behind an opaque asm: otherwise the lane-only parts of the eight offsets below (unit rows, swizzled chunks) are loop
+    // invariants that hipcc keeps in registers through the K loop - which has none to spare, so it spilled them and reloaded them HERE, in the
+    // hand-over K-tile, behind a vmcnt(0) that drained the LDS-DMA ring once per output tile
+    int lane_s = lane;
+    asm volatile("; stage tile" : "+v"(lane_s));
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ur = (wid * 2 + i) * 8 + (lane >> 3);       // row inside the unit
-        const int chunk = (lane & 7) ^ ((ur >> 1) & 7);        // source-side swizzle
+        const int ur = (wid * 2 + i) * 8 + (lane_s >> 3);       // row inside the unit
+        const int chunk = (lane_s & 7) ^ ((ur >> 1) & 7);        // source-side swizzle
         if (j == 0 || j == 3) {                                // A: unit row = wave row (ur >> 5) x 32 rows of this m-half
           int gm = tm * BM + (ur >> 5) * 64 + (j == 3 ? 32 : 0) + (ur & 31);
           gm = gm < p.M ? gm : p.M - 1;
@@ -386,7 +413,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     asm volatile("" : "+s"(tile_m), "+s"(tile_n));
     const int m_base = tile_m * BM + wm * 64;      // + 16 i + row
     const int n_base = tile_n * BN + wn * 128;     // + 64 h + 8 c8 (W-row index of the accumulator columns)
-    if constexpr (FP8) {
+    // fp8 dequantisation: acc * (a_scale[m] * w_scale[n]).  The plain-store / column scale + residual tail (TAIL_FAST: wo, w2) applies it in the
+    // ROW layout behind the LDS transposition (8 row scales + 16 column scales per lane instead of 4 + 32, and no 256 multiplies on the
+    // accumulators while everything else is still live: this instantiation spilled 49 VGPRs); the tails that compute in the accumulator layout
+    // (SwiGLU pairs, head norm / RoPE) and the generic ones dequantise there.
+    constexpr bool IS_FAST = TAIL == TAIL_FAST || TAIL == TAIL_FASTR;
+    constexpr bool ROWDEQ = FP8 && IS_FAST;
+    if constexpr (FP8 && !ROWDEQ) {
       // dequantise in the accumulator layout: lane_e holds C[m_base + 16 i + fr_e][n_base + 16 jn + 4 fg_e + r]
       float sa[4];
 #pragma unroll
@@ -458,194 +491,289 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
         });
       }
     } else if ((TAIL == TAIL_ALL || TAIL == TAIL_QKV) && (TAIL == TAIL_QKV || p.qkv_mode)) {
-      const int D = p.qkv_D;
-      const int sec = (tile_n * BN) / D;            // the whole tile lies in one of q | k | v | gate (D % 256 == 0)
+      // Fused QKV(G) tail.  Like the fast tail below it comes in BRANCH-FREE forms, one per (section kind, interior | edge tile), picked by
+      // wave-uniform branches OUTSIDE the code that touches memory: a load or store behind a branch - the former `if (sec < 2)` / `if (do_rope)`
+      // around the rope / norm-weight requests, the per-lane `if (m < M)` around every store - leaves hipcc's wait-count pass guessing at the
+      // joins, and it answered with `s_waitcnt vmcnt(0)` at every piece, at the tile end, at the head of the next tile and inside the K-tiles of
+      // the tile hand-over, where it drains the LDS-DMA ring (round 3, read off the ISA).  Edge tiles (ragged last row of tiles, or a sequence
+      // length that is not a multiple of 8 in the V section) issue their predicated stores from inline asm (hidden_store*), see the fast tail.
+      // the tail's arguments are read from the kernarg segment HERE (scalar loads behind an opaque pointer) instead of living in SGPRs through the
+      // K loop: with them the kernel needed more than the 102 SGPRs there are and kept the LDS-DMA cursors in VGPRs (v_readfirstlane before every
+      // DMA pair, two VGPR pairs spilled around the K loop)
+      kargs_t pk = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("; epilogue arguments" : "+s"(pk));
+      const int D = pk->qkv_D;
+      const int sec = (tile_n * BN) / D;            // the whole tile lies in one of q | k | v | gate (D % 256 == 0, so n < N everywhere)
+      const bool full = m_base + 64 <= pk->M;         // wave-uniform
       if (sec == 2) {
         // V: Vt[b][h * 128 + d][token]; this wave holds 64 tokens x the 128 d of one head.  Per 16 d (fragment jn) the
         // four token fragments go through the private area as [d][token] and leave as 8 tokens per lane_e.
         const int hd_base = n_base - 2 * D;
+        auto vsec = [&](auto fullc) __attribute__((always_inline)) {
+          constexpr bool FULL = decltype(fullc)::value != 0;      // interior tile and S % 8 == 0: every lane stores 8 whole tokens of one batch row
+          form_lane<32 + FULL>(lane_e, fr_e, fg_e);
 #pragma unroll
-        for (int jn = 0; jn < 8; ++jn) {
+          for (int jn = 0; jn < 8; ++jn) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + ((16 * i + fr_e) ^ (16 * fg_e))] = Num<T>::rnd(acc[i][jn][r]);     // token ^ 16 (d >> 2): the four
-#pragma unroll                                                                                                               // fg groups of a ds_write_b32 hit 4 bank groups, not 1
-          for (int it = 0; it < 2; ++it) {
-            const int dl = it * 8 + (lane_e >> 3), t8 = lane_e & 7;
-            const int tsw = (8 * t8) ^ (16 * (dl >> 2));
-            const f32x4 a = *(const f32x4*)(my + dl * 64 + tsw);
-            const f32x4 b = *(const f32x4*)(my + dl * 64 + tsw + 4);
-            const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            const int m = tile_m * BM + wm * 64 + 8 * t8;
-            const int hd = hd_base + 16 * jn + dl;
-            if (m < p.M) {
-              const int bq = m / p.qkv_S, sidx = m - bq * p.qkv_S;
-              T* dst = (T*)p.vt + (long)bq * p.vt_row_stride + (long)hd * p.vt_ld + sidx;
-              if ((p.qkv_S & 7) == 0 && m + 7 < p.M) {
-                *(uint4*)dst = pack8_bf16(y);
-              } else {
-                for (int e = 0; e < 8 && m + e < p.M; ++e) {
-                  const int bb = (m + e) / p.qkv_S, ss = (m + e) - bb * p.qkv_S;
-                  ((T*)p.vt)[(long)bb * p.vt_row_stride + (long)hd * p.vt_ld + ss] = Num<T>::st(y[e]);
+              for (int r = 0; r < 4; ++r) my[(4 * fg_e + r) * 64 + ((16 * i + fr_e) ^ (16 * fg_e))] = Num<T>::rnd(acc[i][jn][r]);     // token ^ 16 (d >> 2): the four
+#pragma unroll                                                                                                                 // fg groups of a ds_write_b32 hit 4 bank groups, not 1
+            for (int it = 0; it < 2; ++it) {
+              const int dl = it * 8 + (lane_e >> 3), t8 = lane_e & 7;
+              const int tsw = (8 * t8) ^ (16 * (dl >> 2));
+              const f32x4 a = *(const f32x4*)(my + dl * 64 + tsw);
+              const f32x4 b = *(const f32x4*)(my + dl * 64 + tsw + 4);
+              const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+              const int m = tile_m * BM + wm * 64 + 8 * t8;
+              const int hd = hd_base + 16 * jn + dl;
+              if constexpr (FULL) {
+                const int bq = m / pk->qkv_S, sidx = m - bq * pk->qkv_S;
+                *(uint4*)((T*)pk->vt + (long)bq * pk->vt_row_stride + (long)hd * pk->vt_ld + sidx) = pack8_bf16(y);
+              } else if (m < pk->M) {
+                const int bq = m / pk->qkv_S, sidx = m - bq * pk->qkv_S;
+                T* dst = (T*)pk->vt + (long)bq * pk->vt_row_stride + (long)hd * pk->vt_ld + sidx;
+                if ((pk->qkv_S & 7) == 0 && m + 7 < pk->M) {
+                  hidden_store16(dst, pack8_bf16(y));
+                } else {
+                  for (int e = 0; e < 8 && m + e < pk->M; ++e) {
+                    const int bb = (m + e) / pk->qkv_S, ss = (m + e) - bb * pk->qkv_S;
+                    hidden_store2((T*)pk->vt + (long)bb * pk->vt_row_stride + (long)hd * pk->vt_ld + ss, Num<T>::st(y[e]));
+                  }
                 }
               }
             }
           }
-        }
+        };
+        if (full && (pk->qkv_S & 7) == 0) vsec(IC<1>{}); else vsec(IC<0>{});
       } else {
         // q | k | gate sections.  The rope values (cos, sin) and norm weights of a 16-token x 64-column piece are requested
-        // as ONE batch (four 16-byte + four 8-byte loads) in front of its arithmetic: one exposed L2 round trip per piece
+        // as ONE batch (four 16-byte + four 8-byte loads) in front of its arithmetic: one L2 round trip per piece
         // instead of one per 16-column fragment (in-situ: the loads issued one at a time cost 91 us of a 543 us launch at
         // M = 15360).  Larger batches (a whole row, or a row ahead) pushed the kernel over its 256 registers and spilled
         // the accumulators.
         const int nd0 = n_base - sec * D;        // h * 128 (d = 16 jn + 4 fg_e + r)
-        const bool do_rope = sec < 2 && (nd0 >> 7) < p.rope_heads;
+        auto qkg = [&](auto normc, auto ropec, auto actc, auto fullc) __attribute__((always_inline)) {
+          constexpr bool NORM = decltype(normc)::value != 0, ROPE = decltype(ropec)::value != 0, ACT = decltype(actc)::value != 0, FULL = decltype(fullc)::value != 0;
+          constexpr int FORM = 16 + NORM * 8 + ROPE * 4 + ACT * 2 + FULL;
+          form_lane<FORM>(lane_e, fr_e, fg_e);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 yv[8];
+          for (int i = 0; i < 4; ++i) {
+            f32x4 yv[8];
 #pragma unroll
-          for (int jn = 0; jn < 8; ++jn)
+            for (int jn = 0; jn < 8; ++jn) {
+              form_touch<FORM>(acc[i][jn]);      // (the rounding and the sum of squares below are the same in four forms: keep them IN the forms)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
-          if (sec == 3 && p.qkv_gate_act) {      // the attention epilogue's sigmoid, moved here (same operations on the same bf16 values)
+              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(acc[i][jn][r]);
+            }
+            if constexpr (ACT) {      // the attention epilogue's sigmoid, moved here (same operations on the same bf16 values)
 #pragma unroll
-            for (int jn = 0; jn < 8; ++jn)
+              for (int jn = 0; jn < 8; ++jn)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(sigmoid_fast(yv[jn][r]));
-          }
-          float rs = 0.f;
-          const float4* rp = nullptr;
-          if (sec < 2) {
-            // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
-            // lane_e, the other 96 in lanes fr_e + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
-            float ss = 0.f;
+                for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(sigmoid_fast(yv[jn][r]));
+            }
+            float rs = 0.f;
+            const float4* rp = nullptr;
+            if constexpr (NORM) {
+              // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
+              // lane_e, the other 96 in lanes fr_e + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
+              float ss = 0.f;
 #pragma unroll
-            for (int jn = 0; jn < 8; ++jn)
+              for (int jn = 0; jn < 8; ++jn)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) ss += yv[jn][r] * yv[jn][r];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            rs = rsqrtf(ss / 128.0f + p.qk_eps);
-            const int m = m_base + 16 * i + fr_e;
-            const int pos = p.pos0 + m % p.qkv_S;
-            rp = (const float4*)((const float2*)p.rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
-          }
+                for (int r = 0; r < 4; ++r) ss += yv[jn][r] * yv[jn][r];
+              ss += __shfl_xor(ss, 16, 64);
+              ss += __shfl_xor(ss, 32, 64);
+              rs = rsqrtf(ss / 128.0f + pk->qk_eps);
+              const int m = m_base + 16 * i + fr_e;
+              const int pos = pk->pos0 + m % pk->qkv_S;
+              rp = (const float4*)((const float2*)pk->rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
+            }
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (sec < 2) {
-              float4 cs[4];
-              uint2 w4p[4];
-              const T* wp = (const T*)p.qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg_e;
+            for (int h = 0; h < 2; ++h) {
+              if constexpr (NORM) {
+                float4 cs[4];
+                uint2 w4p[4];
+                const T* wp = (const T*)pk->qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg_e;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
-              if (do_rope) {
+                for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
+                if constexpr (ROPE) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h + j)];
-              }
-              __builtin_amdgcn_sched_barrier(0);
+                  for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h + j)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int jn = 4 * h + j;
-                float w4[4];
-                Vec4<T>::unpack(w4p[j], w4);
+                for (int j = 0; j < 4; ++j) {
+                  const int jn = 4 * h + j;
+                  float w4[4];
+                  Vec4<T>::unpack(w4p[j], w4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
-                if (do_rope) {
-                  const float4 c4 = cs[j];                       // two (cos, sin) pairs
-                  const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
-                  yv[jn][0] = __fsub_rn(__fmul_rn(a0, c4.x), __fmul_rn(b0, c4.y));
-                  yv[jn][1] = __fadd_rn(__fmul_rn(a0, c4.y), __fmul_rn(b0, c4.x));
-                  yv[jn][2] = __fsub_rn(__fmul_rn(a1, c4.z), __fmul_rn(b1, c4.w));
-                  yv[jn][3] = __fadd_rn(__fmul_rn(a1, c4.w), __fmul_rn(b1, c4.z));
+                  for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(__fmul_rn(__fmul_rn(yv[jn][r], rs), w4[r]));
+                  if constexpr (ROPE) {
+                    const float4 c4 = cs[j];                       // two (cos, sin) pairs
+                    const float a0 = yv[jn][0], b0 = yv[jn][1], a1 = yv[jn][2], b1 = yv[jn][3];
+                    yv[jn][0] = __fsub_rn(__fmul_rn(a0, c4.x), __fmul_rn(b0, c4.y));
+                    yv[jn][1] = __fadd_rn(__fmul_rn(a0, c4.y), __fmul_rn(b0, c4.x));
+                    yv[jn][2] = __fsub_rn(__fmul_rn(a1, c4.z), __fmul_rn(b1, c4.w));
+                    yv[jn][3] = __fadd_rn(__fmul_rn(a1, c4.w), __fmul_rn(b1, c4.z));
+                  }
                 }
               }
+              const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
+              rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
+                const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+                if constexpr (FULL) *(uint4*)(C + (long)m * pk->ldc + n0) = pack8_bf16(y);
+                else if (m < pk->M) hidden_store16(C + (long)m * pk->ldc + n0, pack8_bf16(y));
+              });
             }
-            const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
-            rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
-              const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
-              if (m < p.M && n0 < p.N) *(uint4*)(C + (long)m * p.ldc + n0) = pack8_bf16(y);
-            });
-          }
+            __builtin_amdgcn_sched_barrier(0);      // one 16-row block at a time: without the fence the scheduler starts the next block's rounding / sum of squares under this
+          }                                         // block's second half and the form needs ~10 more registers than it has (23 spills per form, each reload a vmcnt(0))
+        };
+        const bool do_rope = sec < 2 && (nd0 >> 7) < pk->rope_heads;
+        if (sec < 2) {
+          if (do_rope) { if (full) qkg(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}); else qkg(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}); }
+          else         { if (full) qkg(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}); else qkg(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
+        } else if (pk->qkv_gate_act) {
+          if (full) qkg(IC<0>{}, IC<0>{}, IC<1>{}, IC<1>{}); else qkg(IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{});
+        } else {
+          if (full) qkg(IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}); else qkg(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{});
         }
       }
     } else if (TAIL == TAIL_QKV) {
       // (this instantiation is only launched with qkv_mode set)
-    } else if (TAIL == TAIL_FAST || (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7)) {
+    } else if (IS_FAST || (p.acc_scale == 1.0f && !p.bias && p.div == 0.0f && p.act == 0 && !p.vec_mod && DIAG != 7)) {
       // fast path of the big EchoDiT linears: y = T(acc) [* colscale] [+ residual].  Fully unrolled (static accumulator
       // reads), addresses hoisted: one 64-bit per-lane_e offset per tile, everything else wave-uniform; the residual rows of
       // a piece are requested before its LDS round trip; interior tiles skip the per-element bounds tests.
-      const int row0 = lane_e >> 3, c8 = lane_e & 7;
+      //
+      // COMPILE-TIME forms (TAIL_FAST: no column scale, no residual; TAIL_FASTR: both - wo, w2) x (interior tile | edge tile): with the
+      // column scale / residual / bounds decisions taken at run time, every load and store of this tail sat behind a wave-uniform branch,
+      // hipcc's wait-count pass lost track of how many memory operations were in flight at the joins and put `s_waitcnt vmcnt(0)` in front of
+      // every use of a residual chunk, behind every store and at the head of the next tile (round 3, read off the ISA: 10 vmcnt(0) in this
+      // tail against none in the SwiGLU one): each of the 16 stores of a wave was waited for before the next piece started, the residual
+      // prefetch bought nothing (depth 1 / 3 / 7 measured equal) and the LDS-DMA look-ahead of the next tile was drained at every hand-over.
+      // The branch-free forms let the compiler count: stores are fire and forget, residual chunks arrive a piece ahead.  A PREDICATED store is
+      // enough to lose it again (measured on the ISA: with per-lane `if (m < M)` stores in the edge form the vmcnt(0)s were back, one of them at
+      // the head of the steady K loop, where it drains the LDS-DMA ring at every K-tile).  So the edge form (last, ragged row of tiles; these two
+      // instantiations are launched with N % 256 == 0 only) loads its residual chunks unconditionally from clamped rows and issues its
+      // predicated stores from inline asm, which the wait-count pass does not see: the hardware counter then runs AHEAD of the compiler's
+      // count by the stores issued, so every counted wait of the compiler waits for at least what it meant to wait for (in-order vmcnt).
+      // (Storing rows >= M to row M - 1 again - they hold its values bit for bit - is not an option: the engine's residual is in place, so a
+      // second read-modify-write of row M - 1 would add the residual twice.)
       const bool full = m_base + 64 <= p.M && n_base + 128 <= p.N;          // wave-uniform
-      const long off0 = (long)(m_base + row0) * p.ldc + n_base + 8 * c8;
-      const long roff0 = (long)(m_base + row0) * p.ldres + n_base + 8 * c8;
       const T* const resp = p.res ? (const T*)p.res + zo * p.res_bo + zi * p.res_bi : nullptr;
-      float cs[2][8];
-      if (p.colscale) {
+      auto fast_tail = [&](auto csc, auto rsc, auto fullc) __attribute__((always_inline)) {
+        constexpr int CSM = decltype(csc)::value, RSM = decltype(rsc)::value, FM = decltype(fullc)::value;   // 0 = no, 1 = yes, 2 = ask the arguments
+        form_lane<64 + CSM * 9 + RSM * 3 + FM>(lane_e, fr_e, fg_e);
+        const bool has_cs = CSM == 2 ? p.colscale != nullptr : CSM == 1;
+        const bool has_res = RSM == 2 ? resp != nullptr : RSM == 1;
+        auto inb = [&](int m, int n0) __attribute__((always_inline)) { return FM == 1 ? true : FM == 2 ? (full || (m < p.M && n0 < p.N)) : (m < p.M && n0 < p.N); };
+        const int row0 = lane_e >> 3, c8 = lane_e & 7;
+        const long off0 = (long)(m_base + row0) * p.ldc + n_base + 8 * c8;
+        const long roff0 = (long)(m_base + row0) * p.ldres + n_base + 8 * c8;
+        float cs[2][8];
+        float dq_w[2][8], dq_a[4][2];      // ROWDEQ: w_scale of this lane's 2 x 8 columns, a_scale of its 8 rows
+        if constexpr (ROWDEQ) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int n0 = n_base + 64 * h + 8 * c8;
-          unpack8_bf16(n0 < p.N ? *(const uint4*)((const T*)p.colscale + n0) : uint4{0, 0, 0, 0}, cs[h]);
-        }
-      }
-      // the residual chunks of piece pc + 1 are requested before piece pc goes through LDS and is stored: a load issued
-      // behind a store would wait for that store's round trip too (one in-order vmcnt), once per piece
-      // RES_AHEAD pieces of residual are in flight (measured round 3 with 1 / 3 / 7: no difference, wo 446 / 432-445 / 437-449 us at M = 46080)
-      constexpr int RES_AHEAD = PP_RES_AHEAD, RQN = RES_AHEAD + 1;
-      uint4 rq[RQN][2];
-      auto load_res = [&](int pc, uint4 (&r)[2]) __attribute__((always_inline)) {
-        const int i = pc >> 1, h = pc & 1;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          r[it] = uint4{0, 0, 0, 0};
-          const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
-          if (resp && (full || (m < p.M && n0 < p.N))) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
-        }
-      };
-#pragma unroll
-      for (int a = 0; a < RES_AHEAD && a < 8; ++a) load_res(a, rq[a % RQN]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int pc = 2 * i + h;
-          if (pc + RES_AHEAD < 8) load_res(pc + RES_AHEAD, rq[(pc + RES_AHEAD) % RQN]);
-          const uint4 (&rr)[2] = rq[pc % RQN];
-          if constexpr (DIAG != 9) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = acc[i][4 * h + c];
+          for (int h = 0; h < 2; ++h) {
+            const int n0 = n_base + 64 * h + 8 * c8;
+            const float* wsp = p.w_scale + (n0 + 7 < p.Npad ? n0 : p.Npad - 8);
+            const f32x4 w0 = *(const f32x4*)wsp, w1 = *(const f32x4*)(wsp + 4);
+            dq_w[h][0] = w0[0]; dq_w[h][1] = w0[1]; dq_w[h][2] = w0[2]; dq_w[h][3] = w0[3];
+            dq_w[h][4] = w1[0]; dq_w[h][5] = w1[1]; dq_w[h][6] = w1[2]; dq_w[h][7] = w1[3];
           }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int m = m_base + 16 * i + 8 * it + row0;
+              const float av = *(p.a_scale ? p.a_scale + (m < p.M ? m : p.M - 1) : p.w_scale);      // always a load (no branch around it), from a valid address
+              dq_a[i][it] = p.a_scale ? av : p.a_scale_const;
+            }
+        }
+        if (has_cs) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n0 = n_base + 64 * h + 8 * c8;
+            unpack8_bf16(*(const uint4*)((const T*)p.colscale + (FM != 2 || n0 < p.N ? n0 : p.N - 8)), cs[h]);
+          }
+        }
+        // the residual chunks of piece pc + 1 are requested before piece pc goes through LDS and is stored: a load issued
+        // behind a store would wait for that store's round trip too (one in-order vmcnt), once per piece
+        constexpr int RES_AHEAD = PP_RES_AHEAD, RQN = RES_AHEAD + 1;
+        uint4 rq[RQN][2];
+        auto load_res = [&](int pc, uint4 (&r)[2]) __attribute__((always_inline)) {
+          const int i = pc >> 1, h = pc & 1;
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
-            const int row = it * 8 + row0;
-            f32x4 a, b;
-            if constexpr (DIAG == 9) { a = acc[i][4 * h + 2 * it]; b = acc[i][4 * h + 2 * it + 1]; }      // timing experiment: no LDS round trip (wrong layout)
-            else {
-              a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
-              b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+            r[it] = uint4{0, 0, 0, 0};
+            const int m = m_base + 16 * i + 8 * it + row0, n0 = n_base + 64 * h + 8 * c8;
+            if constexpr (FM == 2) {
+              if (has_res && inb(m, n0)) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
+            } else if (has_res) {
+              if constexpr (FM == 1) r[it] = *(const uint4*)(resp + roff0 + (long)(16 * i + 8 * it) * p.ldres + 64 * h);
+              else r[it] = *(const uint4*)(resp + (long)(m < p.M ? m : p.M - 1) * p.ldres + n0);      // edge tile: row M - 1 again, see above
             }
-            float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e]);
-            if (p.colscale) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] * cs[h][e]);
-            }
-            if (resp) {
-              float r[8];
-              unpack8_bf16(rr[it], r);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] + r[e]);
-            }
-            const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
-            if constexpr (DIAG == 8) {           // timing experiment: the fast-path epilogue without its global stores
-              const uint4 pk = pack8_bf16(y);
-              asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
-            } else
-            if (full || (m < p.M && n0 < p.N)) *(uint4*)(C + off0 + (long)(16 * i + 8 * it) * p.ldc + 64 * h) = pack8_bf16(y);
           }
-        }
-    } else if constexpr (TAIL != TAIL_FAST) {
+        };
+#pragma unroll
+        for (int a = 0; a < RES_AHEAD && a < 8; ++a) load_res(a, rq[a % RQN]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int pc = 2 * i + h;
+            if (pc + RES_AHEAD < 8) load_res(pc + RES_AHEAD, rq[(pc + RES_AHEAD) % RQN]);
+            const uint4 (&rr)[2] = rq[pc % RQN];
+            if constexpr (DIAG != 9) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) *(f32x4*)(my + (fr_e * 16 + ((c * 4 + fg_e) ^ fr_e)) * 4) = acc[i][4 * h + c];
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int row = it * 8 + row0;
+              f32x4 a, b;
+              if constexpr (DIAG == 9) { a = acc[i][4 * h + 2 * it]; b = acc[i][4 * h + 2 * it + 1]; }      // timing experiment: no LDS round trip (wrong layout)
+              else {
+                a = *(const f32x4*)(my + (row * 16 + ((2 * c8) ^ row)) * 4);
+                b = *(const f32x4*)(my + (row * 16 + ((2 * c8 + 1) ^ row)) * 4);
+              }
+              float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+              if constexpr (ROWDEQ) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] *= dq_a[i][it] * dq_w[h][e];      // the same two fp32 products as the accumulator-layout form
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e]);
+              if (has_cs) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] * cs[h][e]);
+              }
+              if (has_res) {
+                float r[8];
+                unpack8_bf16(rr[it], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = Num<T>::rnd(y[e] + r[e]);
+              }
+              const int m = m_base + 16 * i + row, n0 = n_base + 64 * h + 8 * c8;
+              if constexpr (DIAG == 8) {           // timing experiment: the fast-path epilogue without its global stores
+                const uint4 pk = pack8_bf16(y);
+                asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+              } else
+              if constexpr (FM == 0) {
+                if (m < p.M) hidden_store16(C + (long)m * p.ldc + n0, pack8_bf16(y));
+              } else if (inb(m, n0)) *(uint4*)(C + off0 + (long)(16 * i + 8 * it) * p.ldc + 64 * h) = pack8_bf16(y);
+            }
+          }
+      };
+      if constexpr (TAIL == TAIL_FAST) {
+        if (full) fast_tail(IC<0>{}, IC<0>{}, IC<1>{}); else fast_tail(IC<0>{}, IC<0>{}, IC<0>{});
+      } else if constexpr (TAIL == TAIL_FASTR) {
+        if (full) fast_tail(IC<1>{}, IC<1>{}, IC<1>{}); else fast_tail(IC<1>{}, IC<1>{}, IC<0>{});
+      } else {
+        fast_tail(IC<2>{}, IC<2>{}, IC<2>{});
+      }
+    } else if constexpr (!IS_FAST) {
       // the tail is emitted once (runtime loop over the 8 pieces); the accumulators of piece 2 i + h are picked by
       // static register reads pinned with an empty asm (merged stores would turn `acc` into a scratch array)
 #pragma unroll 1
@@ -719,7 +847,12 @@ hipError_t launch_pp(const GemmArgs& g, hipStream_t st) {
     static const bool split = getenv("ECHO_PP_TAILS") ? atoi(getenv("ECHO_PP_TAILS")) != 0 : true;
     if (split && g.ksplit <= 1) {
       if (g.qkv_mode) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_QKV>(g, st);
-      if (g.acc_scale == 1.0f && !g.bias && g.div == 0.0f && g.act == 0 && !g.vec_mod) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_FAST>(g, st);
+      if (g.acc_scale == 1.0f && !g.bias && g.div == 0.0f && g.act == 0 && !g.vec_mod) {
+        if (!(g.N & 255)) {      // the branch-free edge form of these two needs whole tile columns
+          if (!g.colscale && !g.res) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_FAST>(g, st);
+          if (g.colscale && g.res) return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_FASTR>(g, st);
+        }
+      }
       return launch_pp_tail<SW, DIAG, LEAD, FP8, TAIL_ROWS>(g, st);
     }
   }
