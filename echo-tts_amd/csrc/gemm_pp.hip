@@ -48,6 +48,7 @@ namespace {
 #endif
 template <int V> struct IC { static constexpr int value = V; };
 
+
 __device__ __forceinline__ uint4 pack8_bf16(const float* y) {
   uint4 r;
   r.x = pack_bf16x2(y[0], y[1]); r.y = pack_bf16x2(y[2], y[3]); r.z = pack_bf16x2(y[4], y[5]); r.w = pack_bf16x2(y[6], y[7]);
@@ -219,9 +220,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     constexpr bool SWITCH = decltype(swc)::value != 0;
     char* dst = smem + buf * KTILE + j * UNIT + wid * 2048;
     const char* base = (j == 0 || j == 3) ? a_cur : w_cur;
+    // the 32-bit per-lane offsets go through an opaque asm at every use: hipcc otherwise zero-extends the eight of them ONCE, outside the
+    // K loop, keeps the 64-bit copies (8 more VGPRs live through the loop) and adds the base on the VALU (two v_lshl_add_u64 per unit); from
+    // a 32-bit value it selects `global_load_lds_dwordx4 voff32, s[base]`
+    unsigned vo0 = voff[j][0], vo1 = voff[j][1];
+    asm volatile("" : "+v"(vo0), "+v"(vo1));
     if (DIAG != 1 || !in_loop) {
-      glds16(base + voff[j][0], dst);
-      glds16(base + voff[j][1], dst + 1024);
+      glds16(base + vo0, dst);
+      glds16(base + vo1, dst + 1024);
     }
     if constexpr (!SWITCH) {
       if (j == 2) w_cur += KBYTES;
@@ -256,7 +262,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   const int w_rd0 = (wn * 64 + fr) * KBYTES + c0, w_rd1 = w_rd0 ^ C1X;   // + unit j1 / j2, + 16 jn rows
 
   f32x4 acc[4][8];                 // [m fragment][n fragment]: lane holds C[m = 16 i + fr][n = 16 jn + 4 fg + r]
-  bf16x8 af[2][2], wf[2][4][2];    // A (i, k-half) of the current m-half; W (n-half, jn, k-half); fp8: (.., 16-byte half of the 32 K bytes)
+  bf16x8 af[2][2], wf[2][4][2];    // bf16: A (i, k-half) of the current m-half; W (n-half, jn, k-half)
+  i32x8 af8[2], wf8[2][4];         // fp8: the lane's 32 K bytes of A (i) / W (n-half, jn) as ONE 8-register operand, assembled where the two 16-byte halves are
+                                   // loaded (assembled at the MFMA instead, hipcc copied every fragment into a fresh tuple: 62 v_mov_b64 per K-tile in the steady loop)
 
   // ---- prologue: the first LEAD units; units 0 and 1 must have landed everywhere before phase 0 reads them
 #pragma unroll
@@ -289,8 +297,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
       const char* wp = sb + (q == 0 ? 1 : 2) * UNIT;
 #pragma unroll
       for (int jn = 0; jn < 4; ++jn) {
-        wf[nh][jn][0] = *(const bf16x8*)(wp + w_rd0 + jn * 16 * KBYTES);
-        wf[nh][jn][1] = *(const bf16x8*)(wp + w_rd1 + jn * 16 * KBYTES);
+        if constexpr (FP8) {
+          const i32x4 lo = *(const i32x4*)(wp + w_rd0 + jn * 16 * KBYTES), hi = *(const i32x4*)(wp + w_rd1 + jn * 16 * KBYTES);
+          wf8[nh][jn] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          wf[nh][jn][0] = *(const bf16x8*)(wp + w_rd0 + jn * 16 * KBYTES);
+          wf[nh][jn][1] = *(const bf16x8*)(wp + w_rd1 + jn * 16 * KBYTES);
+        }
       }
     }
     if constexpr (q == 0) __builtin_amdgcn_sched_barrier(0);
@@ -298,8 +311,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
       const char* ap = sb + (q == 0 ? 0 : 3) * UNIT;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i][0] = *(const bf16x8*)(ap + a_rd0 + i * 16 * KBYTES);
-        af[i][1] = *(const bf16x8*)(ap + a_rd1 + i * 16 * KBYTES);
+        if constexpr (FP8) {
+          const i32x4 lo = *(const i32x4*)(ap + a_rd0 + i * 16 * KBYTES), hi = *(const i32x4*)(ap + a_rd1 + i * 16 * KBYTES);
+          af8[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          af[i][0] = *(const bf16x8*)(ap + a_rd0 + i * 16 * KBYTES);
+          af[i][1] = *(const bf16x8*)(ap + a_rd1 + i * 16 * KBYTES);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -327,10 +345,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     if constexpr (FP8) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, af[i][0]), __builtin_bit_cast(i32x4, af[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 a8 = af8[i];
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) {
-          const i32x8 w8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wf[nh][jn][0]), __builtin_bit_cast(i32x4, wf[nh][jn][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          const i32x8 w8 = wf8[nh][jn];
           // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0 in every byte (the row scales are applied in the epilogue)
           acc[2 * mh + i][4 * nh + jn] =
               __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[2 * mh + i][4 * nh + jn], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
