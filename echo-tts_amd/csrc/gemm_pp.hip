@@ -48,6 +48,9 @@ namespace {
 #endif
 template <int V> struct IC { static constexpr int value = V; };
 
+// lane id of this thread inside its wave, from the hardware (two VALU operations, no register carried from kernel entry)
+__device__ __forceinline__ int hw_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 
 __device__ __forceinline__ uint4 pack8_bf16(const float* y) {
   uint4 r;
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     // the lane coordinate behind an opaque asm: otherwise the lane-only parts of the eight offsets below (unit rows, swizzled chunks) are loop
     // invariants that hipcc keeps in registers through the K loop - which has none to spare, so it spilled them and reloaded them HERE, in the
     // hand-over K-tile, behind a vmcnt(0) that drained the LDS-DMA ring once per output tile
-    int lane_s = lane;
+    int lane_s = hw_lane();      // (from mbcnt, not from `lane`: that variable would be spilled at kernel entry and reloaded here - behind a vmcnt(0))
     asm volatile("; stage tile" : "+v"(lane_s));
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
     if (wid < 4) __builtin_amdgcn_s_barrier();    // level again: both groups run their epilogues side by side
     if constexpr (DIAG == 5) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_loop += n - t_l0; t_l0 = n; ++n_tiles; }
 
-    lane_e = lane;
+    lane_e = hw_lane();
     asm volatile("" : "+v"(lane_e));
     fr_e = lane_e & 15; fg_e = lane_e >> 4;
     // the tile coordinates too: everything the epilogue derives from them (64-bit row offsets of C / the residual, ...) is computed HERE,
