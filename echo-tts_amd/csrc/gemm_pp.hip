@@ -578,6 +578,25 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
           constexpr bool NORM = decltype(normc)::value != 0, ROPE = decltype(ropec)::value != 0, ACT = decltype(actc)::value != 0, FULL = decltype(fullc)::value != 0;
           constexpr int FORM = 16 + NORM * 8 + ROPE * 4 + ACT * 2 + FULL;
           form_lane<FORM>(lane_e, fr_e, fg_e);
+          // the norm weights (4 x 8 bytes) and RoPE values (4 x 16 bytes) of piece (i, h) = 16 tokens x 64 columns are requested as one batch ONE
+          // PIECE AHEAD: behind the arithmetic of the piece before (its own batch is dead by then: same registers) and IN FRONT OF that piece's
+          // stores - the counted wait for the batch then leaves those stores in flight (vmcnt is in order: requested behind them, the batch
+          // could only be waited for together with the stores' round trip, once per piece)
+          float4 cs[4];
+          uint2 w4p[4];
+          auto request = [&](int i_, int h_) __attribute__((always_inline)) {
+            const T* wp = (const T*)pk->qk_w + (long)sec * D + nd0 + 64 * h_ + 4 * fg_e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
+            if constexpr (ROPE) {
+              const int m = m_base + 16 * i_ + fr_e;
+              const int pos = pk->pos0 + m % pk->qkv_S;
+              const float4* rp = (const float4*)((const float2*)pk->rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
+#pragma unroll
+              for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h_ + j)];
+            }
+          };
+          if constexpr (NORM) request(0, 0);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             f32x4 yv[8];
@@ -594,7 +613,6 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
                 for (int r = 0; r < 4; ++r) yv[jn][r] = Num<T>::rnd(sigmoid_fast(yv[jn][r]));
             }
             float rs = 0.f;
-            const float4* rp = nullptr;
             if constexpr (NORM) {
               // per-head RMSNorm (model.py:86-104) on the 128 columns of (token m, this wave's head): 32 values in this
               // lane_e, the other 96 in lanes fr_e + 16, + 32, + 48; then interleaved-pair RoPE on heads < rope_heads
@@ -606,22 +624,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
               ss += __shfl_xor(ss, 16, 64);
               ss += __shfl_xor(ss, 32, 64);
               rs = rsqrtf(ss / 128.0f + pk->qk_eps);
-              const int m = m_base + 16 * i + fr_e;
-              const int pos = pk->pos0 + m % pk->qkv_S;
-              rp = (const float4*)((const float2*)pk->rope + (long)pos * 64) + fg_e;     // pairs 8 jn + 2 fg_e, + 1
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               if constexpr (NORM) {
-                float4 cs[4];
-                uint2 w4p[4];
-                const T* wp = (const T*)pk->qk_w + (long)sec * D + nd0 + 64 * h + 4 * fg_e;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w4p[j] = *(const uint2*)(wp + 16 * j);
-                if constexpr (ROPE) {
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) cs[j] = rp[4 * (4 * h + j)];
-                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -639,6 +645,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
                     yv[jn][3] = __fadd_rn(__fmul_rn(a1, c4.w), __fmul_rn(b1, c4.z));
                   }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (2 * i + h + 1 < 8) request(h ? i + 1 : i, h ? 0 : 1);      // the next piece's batch, in front of this piece's stores
+                __builtin_amdgcn_sched_barrier(0);
               }
               const f32x4 v4[4] = {yv[4 * h], yv[4 * h + 1], yv[4 * h + 2], yv[4 * h + 3]};
               rows(v4, [&](int row, int c8, float (&y)[8]) __attribute__((always_inline)) {
