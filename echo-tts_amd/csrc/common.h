@@ -129,6 +129,8 @@ struct GemmArgs {
   float a_scale_const;
   void* c8; long c8_ld; float c8_inv;
   int pp_gn;                    // gemm_pp_kernel: tile columns per strip of the tile order (0 = default PP_GN)
+  void* sink;                   // optional: >= 256 KiB of device scratch nobody reads; the branch-free conv tails of gemm_nt_kernel (NTAIL >= 2) send the
+                                // stores of their idle threads there instead of predicating them (engine: one per context)
   // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the
   // per-head RMSNorm (weights qk_w = [q_norm | k_norm], each qkv_D) and interleaved-pair RoPE on heads < rope_heads at
   // position pos0 + (m % qkv_S); the v section is written TRANSPOSED to vt[(m / S)][h][d][m % S]; gate is stored as is.

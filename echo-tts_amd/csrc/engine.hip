@@ -225,7 +225,7 @@ struct Engine : EngineBase {
     for (auto& e : nk_ev) if (e) (void)hipEventDestroy(e);
     for (void* p : owned) (void)hipFree(p);
     for (DevBuf* b : all_bufs()) b->release();
-    b_gemm_ws.release(); b_tune_c.release(); b_flush.release();
+    b_gemm_ws.release(); b_tune_c.release(); b_flush.release(); b_sink.release();
   }
 
   // ------------------------------------------------------------------ weights
@@ -1526,9 +1526,12 @@ struct Engine : EngineBase {
   }
 
   bool dac_split3 = getenv("ECHO_DAC_EXACT_FP32") ? atoi(getenv("ECHO_DAC_EXACT_FP32")) == 0 : true;
+  DevBuf b_sink;      // GemmArgs.sink: where the branch-free conv tails send the stores of their idle threads
   int frun(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
     g.split3 = dac_split3 ? 1 : 0;
+    if (!b_sink.p) CK(b_sink.reserve(262144));
+    g.sink = b_sink.p;
     CKI(plan_gemm<float>(g, st));
     return run_planned<float>(g, st, false);
   }

@@ -65,7 +65,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
   const int g_chunk = tid % CPR, g_r0 = tid / CPR;
   const int g_n0 = tile_n * BN + g_chunk * 4;
   const bool g_col_ok = tid < NTA && g_n0 < p.N;
-  const bool generic = NTAIL == 1 ? !SWIGLU : (!(p.ksplit > 1) && !SWIGLU && !p.qkv_mode);
+  const bool generic = NTAIL >= 1 ? !SWIGLU : (!(p.ksplit > 1) && !SWIGLU && !p.qkv_mode);
   float rs_next[ITER][4];
 #pragma unroll
   for (int k = 0; k < ITER; ++k)
@@ -79,7 +79,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
       if (g_col_ok && ml < 32 && mrow + ml < p.M) gemm_tail_res<T>(p, mrow + ml, g_n0, zo, zi, rs_next[k]);
     }
   };
-  if (generic && p.res) fetch_res(0);
+  // conv forms: clamped, unconditional residual loads and the per-column operands read in front of the pass loop
+  auto conv_fetch_res = [&](int pass_) __attribute__((always_inline)) {
+    const int mrow = tile_m * BM + pass_ * 32;
+    const int nc = g_n0 + 3 < p.N ? g_n0 : p.N - 4;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const int ml = g_r0 + k * RPS, mc = mrow + (ml < 32 ? ml : 31);
+      Vec4<T>::unpack(*(const typename Vec4<T>::raw*)((const T*)p.res + zo * p.res_bo + zi * p.res_bi + (long)(mc < p.M ? mc : p.M - 1) * p.ldres + nc), rs_next[k]);
+    }
+  };
+  if constexpr (NTAIL >= 2) {
+    const int nc = g_n0 + 3 < p.N ? g_n0 : p.N - 4;
+    const int nv = p.vec_mod ? nc % p.vec_mod : nc;
+    const long bo = zo * p.bias_bo + zi * p.bias_bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tcols.bias[i] = vec_at<T>(p.bias, bo + nv + i);
+      tcols.al[i] = vec_at<T>(p.snake_alpha, nv + i);
+      tcols.ial[i] = 1.0f / (tcols.al[i] + 1e-9f);
+    }
+    if constexpr (((NTAIL - 2) & 1) != 0) {
+      conv_fetch_res(0);
+      // as many (dummy) stores behind the first pass's residual request as every later pass's request has behind it: the wait-count pass merges
+      // the loop entry with the back edge, and with nothing behind the request on the entry path it waits for the request as the YOUNGEST
+      // operations in flight - on the back edge that includes the previous pass's stores (vmcnt(3..0) instead of vmcnt(7..4), read off the ISA)
+      constexpr int NST = 1 + (((NTAIL - 2) & 2) != 0);
+#pragma unroll
+      for (int k = 0; k < ITER * NST; ++k) *(f32x4*)((char*)p.sink + (k >> 1) * 32768 + tid * 32 + 16 * (k & 1)) = f32x4{0.f, 0.f, 0.f, 0.f};      // distinct addresses: no dead-store elimination
+    }
+  } else if (generic && p.res) fetch_res(0);
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     // raw barriers + lgkmcnt only: __syncthreads() would also wait (vmcnt) for the previous pass's global stores
@@ -179,6 +208,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
           }
           if (m < p.M && n0 < p.N) *(typename Vec4<T>::raw*)(C + (long)m * p.ldc + n0) = Vec4<T>::pack(y);
         }
+      }
+    } else if constexpr (NTAIL >= 2) {
+      // ---- branch-free conv tail (the Fish S1-DAC decoder's Conv1d / ConvTranspose1d launches): y = acc + bias [+ residual],
+      // main output [optional], second output snake(y).  NTAIL = 2 + RES + 2 MAIN.  Nothing that touches memory sits behind a branch:
+      // the residual rows are loaded from clamped addresses, the stores of threads without a row (beyond the tile's last full row of
+      // chunks, beyond M) go to p.sink.  The generic tail below keeps its loads and stores behind the feature tests and per-thread predicates;
+      // hipcc's wait-count pass then cannot count what is in flight at the joins and waits for EVERYTHING (vmcnt(0)) in front of the
+      // residual of every 32-row pass, i.e. for the round trip of the previous pass's stores, BM / 32 times per tile (read off the ISA).
+      constexpr bool F_RES = ((NTAIL - 2) & 1) != 0, F_MAIN = ((NTAIL - 2) & 2) != 0;
+      float rs[ITER][4];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[k][i] = rs_next[k][i];
+      if constexpr (F_RES) { if (pass + 1 < NPASS) conv_fetch_res(pass + 1); }
+      char* const sink = (char*)p.sink + tid * 32;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int ml = g_r0 + k * RPS, m = mrow0 + ml;
+        const bool ok = g_col_ok && ml < 32 && m < p.M;
+        const f32x4 a4 = *(const f32x4*)(slab + slab_pos<CPR>(ml < 32 ? ml : 31, g_chunk) * 4);
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(Num<T>::rnd(a4[i] + tcols.bias[i]));
+        if constexpr (F_RES) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = Num<T>::rnd(y[i] + rs[k][i]);
+        }
+        typedef Vec4<T> V;
+        if constexpr (F_MAIN) *(typename V::raw*)(ok ? (char*)(C + (long)m * p.ldc + g_n0) : sink) = V::pack(y);
+        float sn4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sn = sinf(tcols.al[i] * y[i]);
+          sn4[i] = Num<T>::rnd(y[i] + tcols.ial[i] * (sn * sn));
+        }
+        *(typename V::raw*)(ok ? (char*)(C2 + (long)m * p.ldc + g_n0) : sink + 16) = V::pack(sn4);
       }
     } else {
       const int chunk = g_chunk, r0 = g_r0, n0 = g_n0;
@@ -452,6 +518,14 @@ hipError_t launch_cfg_tail(const GemmArgs& g, hipStream_t st);
 template <typename T, bool SW, typename CF, bool SPLIT3 = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   static const bool split = getenv("ECHO_NT_TAILS") ? atoi(getenv("ECHO_NT_TAILS")) != 0 : true;      // 0: the all-tails instantiation everywhere (A/B aid)
+  if constexpr (SPLIT3 && !SW && (CF::BN == 96 || CF::BN == 192)) {      // the DAC's conv tiles: branch-free conv tails (gemm_epilogue, NTAIL >= 2)
+    static const bool conv = getenv("ECHO_NT_CONV_TAILS") ? atoi(getenv("ECHO_NT_CONV_TAILS")) != 0 : true;
+    if (split && conv && g.ksplit <= 1 && !g.qkv_mode && g.sink && g.bias && g.snake_alpha && g.C2 && !g.colscale && g.act == 0 && g.div == 0.0f &&
+        g.acc_scale == 1.0f && g.N >= 4) {
+      if (g.res) return g.store_main ? launch_cfg_tail<T, SW, CF, SPLIT3, 5>(g, st) : launch_cfg_tail<T, SW, CF, SPLIT3, 3>(g, st);
+      return g.store_main ? launch_cfg_tail<T, SW, CF, SPLIT3, 4>(g, st) : launch_cfg_tail<T, SW, CF, SPLIT3, 2>(g, st);
+    }
+  }
   if (split && g.ksplit <= 1 && !g.qkv_mode) return launch_cfg_tail<T, SW, CF, SPLIT3, 1>(g, st);
   return launch_cfg_tail<T, SW, CF, SPLIT3, 0>(g, st);
 }
