@@ -96,6 +96,9 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x));
 // expf + IEEE division; the fp32 parity engine keeps silu_f
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sin(x) on the hardware transcendental: v_sin_f32 takes revolutions, v_fract_f32 brings them into its domain.  Absolute error ~1e-6 for the
+// |x| < ~100 the Snake activations see (the revolutions lose log2(|x| / 2 pi) bits to the fraction); sinf() costs ~38 VALU instructions here, this 3.
+__device__ __forceinline__ float sin_fast(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189532f)); }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // bf16 outputs only (see silu_fast)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -129,6 +132,7 @@ struct GemmArgs {
   float a_scale_const;
   void* c8; long c8_ld; float c8_inv;
   int pp_gn;                    // gemm_pp_kernel: tile columns per strip of the tile order (0 = default PP_GN)
+  int snake_fast;               // conv tails (NTAIL >= 2): Snake with sin_fast() instead of sinf() (engine: ECHO_DAC_FAST_SIN)
   void* sink;                   // optional: >= 256 KiB of device scratch nobody reads; the branch-free conv tails of gemm_nt_kernel (NTAIL >= 2) send the
                                 // stores of their idle threads there instead of predicating them (engine: one per context)
   // fused QKV(G) epilogue (model.py:217-232 / 132-142): the N axis is [q | k | v | gate] x qkv_D.  q and k sections get the

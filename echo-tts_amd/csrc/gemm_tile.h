@@ -241,7 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* slab, in
         float sn4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float sn = sinf(tcols.al[i] * y[i]);
+          const float sn = p.snake_fast ? sin_fast(tcols.al[i] * y[i]) : sinf(tcols.al[i] * y[i]);
           sn4[i] = Num<T>::rnd(y[i] + tcols.ial[i] * (sn * sn));
         }
         *(typename V::raw*)(ok ? (char*)(C2 + (long)m * p.ldc + g_n0) : sink + 16) = V::pack(sn4);
