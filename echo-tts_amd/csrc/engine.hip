@@ -1528,7 +1528,7 @@ struct Engine : EngineBase {
   bool dac_split3 = getenv("ECHO_DAC_EXACT_FP32") ? atoi(getenv("ECHO_DAC_EXACT_FP32")) == 0 : true;
   // Snake of the conv tails on v_sin_f32 (common.h sin_fast) unless ECHO_DAC_FAST_SIN=0: full-size decode of 640 frames, waveform against the
   // sinf() build: 4.8e-8 RMS / 2.5e-7 max on a 1.05e-2 RMS signal (tools/dac_sin_check.py) - the size of the split-3 path's own distance to the
-  // oracle, three orders inside the 1e-4 waveform tolerance; sinf() was ~38 VALU instructions per output element of every conv
+  // CPU restatement, three orders inside the 1e-4 waveform tolerance; sinf() was ~38 VALU instructions per output element of every conv
   bool dac_fast_sin = getenv("ECHO_DAC_FAST_SIN") ? atoi(getenv("ECHO_DAC_FAST_SIN")) != 0 : true;
   DevBuf b_sink;      // GemmArgs.sink: where the branch-free conv tails send the stores of their idle threads
   int frun(const GemmArgs& g_in, hipStream_t st) {
