@@ -13,6 +13,12 @@ SOURCES = ["gemm_pp.hip", "gemm.hip", "gemm_f32.hip", "attention.hip", "elementw
 # attention.hip: the one-wave-per-SIMD kernel places every VALU instruction in an MFMA gap by hand; SLP vectorisation would turn its
 # scalar fp32 adds into v_pk_add_f32 plus the v_mov shuffles that feed them (cdna_hip_programming.md Appendix B, pitfalls)
 EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+# No floating-point contraction: hipcc's default (fast-honor-pragmas) fuses a * c - b * s into an fma wherever it likes, and it liked different
+# places in two copies of the same epilogue (the interior-tile and edge-tile forms of gemm_pp's fused QKV tail): a token's RoPE output then depended
+# on which tile of the launch it sat in (1-4 elements per launch one bf16 ulp apart; caught by the row-permutation test).  Every rounding point of
+# the reference's arithmetic (a * c - b * s, the Euler update, x * rs * w, ...) is a separate instruction now, in every kernel; the fused
+# multiply-adds that are wanted are written as fmaf().
+COMMON_FLAGS = ["-ffp-contract=off"]
 
 
 def _hipcc() -> str:
@@ -38,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + COMMON_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     for src, p in procs:

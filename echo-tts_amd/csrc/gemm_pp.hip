@@ -65,10 +65,11 @@ __device__ __forceinline__ void unpack8_bf16(uint4 r, float* f) {
 }
 
 // global stores the compiler's wait-count pass does not see (edge tiles of the branch-free tails, see gemm_pp_kernel's fast tail): the hardware
-// vmcnt then runs ahead of the compiler's count, so its counted waits wait for at least what they meant to.  s_nop: the store-data hazard slot.
+// vmcnt then runs ahead of the compiler's count, so its counted waits wait for at least what they meant to.  s_nop: the store-data hazard slots
+// the compiler's hazard recogniser would have kept (2 wait states on gfx940+ for a store of more than 64 bits, none needed for 16 bits).
 __device__ __forceinline__ void hidden_store16(void* dst, uint4 pk) {
   const i32x4 pv = {(int)pk.x, (int)pk.y, (int)pk.z, (int)pk.w};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" :: "v"(dst), "v"(pv) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(pv) : "memory");      // 2 wait states before a VALU may overwrite the data of a > 64-bit store (gfx940+)
 }
 __device__ __forceinline__ void hidden_store2(void* dst, bf16_t v) {
   const int iv = v;

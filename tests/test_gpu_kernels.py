@@ -676,6 +676,39 @@ def test_gemm_pingpong_fused_qkv_tail_multi_tile(rows, S):
         U.bf16_close(out2[:, 3 * D:], torch.sigmoid(gte.float()).bfloat16(), ulps=1.0, frac_exact=0.995)
 
 
+@pytest.mark.parametrize("B,S", [(24, 640), (5, 200), (7, 100), (3, 37)])
+def test_gemm_pingpong_fused_qkv_tail_is_equivariant_under_row_block_permutation(B, S):
+    """A token's q / k / v / gate must not depend on WHERE in the launch it sits: the same B sequences in another order give the same bits,
+    with random (non-integer) operands, RoPE on half the heads, and sequence lengths that leave a ragged last tile and make 16-row blocks
+    straddle sequences.  Round 3 finding: the interior-tile and the edge-tile copy of the fused tail are compiled separately, and with hipcc's
+    default floating-point contraction each copy fused a * c - b * s into an fma in its own way - 1-4 RoPE outputs per launch came out one
+    bf16 ulp apart depending on the tile a token was in (the library is built with -ffp-contract=off since)."""
+    D, K = 2048, 2048
+    M, N = B * S, 4 * D
+    g = torch.Generator().manual_seed(3)
+    A = (torch.rand((M + 256, K), generator=g) * 2 - 1).to(torch.bfloat16).to(DEV)
+    W = ((torch.rand((N, K), generator=g) * 2 - 1) * 0.05).to(torch.bfloat16).to(DEV)
+    qk_w = (1 + 0.1 * torch.randn((2 * D,), generator=g)).to(torch.bfloat16).to(DEV)
+    ang = torch.rand((S, 64), generator=g).to(DEV)
+    rope = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous()
+    S8 = (S + 7) // 8 * 8
+
+    def go(a):
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        vt = torch.zeros((B, D, S8), dtype=torch.bfloat16, device=DEV)
+        U.gemm(a, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, Npad=N, cfg=5,
+               qkv=dict(D=D, S=S, rope_heads=8, pos0=0, eps=1e-6, qk_w=qk_w, rope=rope, vt=vt, vt_ld=S8, vt_row_stride=D * S8, gate_act=1))
+        return out, vt
+
+    out0, vt0 = go(A)
+    perm = torch.randperm(B, generator=g)
+    Ap = A.clone()
+    Ap[:M] = A[:M].view(B, S, K)[perm.to(DEV)].reshape(M, K)
+    out1, vt1 = go(Ap)
+    assert torch.equal(out1, out0.view(B, S, N)[perm.to(DEV)].reshape(M, N))
+    assert torch.equal(vt1[:, :, :S], vt0[perm.to(DEV)][:, :, :S])
+
+
 @pytest.mark.parametrize("cfg", [5, 4, 2, 0, 104, 106, 107])
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (2560, 2048, 2048), (1000, 640, 2048)])
 def test_gemm_operands_flush_against_the_end_of_their_allocation(cfg, M, N, K):
