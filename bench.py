@@ -180,7 +180,7 @@ def cpu_baseline(threads: int, state, pca, ids, tmask, spk, smask):
         R.ae_decode(dw, dcfg, pc, lat)
         tdac = time.perf_counter() - t0
     est = tenc + 20 * t3 + 20 * t1 + tdac * (S / nf)
-    return {"value": AUDIO_S / est, "unit": "audio-s/s", "cores": threads, "kind": "port",
+    return {"value": AUDIO_S / est, "unit": "audio-s/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle/echo_ref.py, torch {torch.__version__} CPU eager, bf16 EchoDiT + fp32 DAC, the bench's 24-layer weights and inputs: "
                       f"text + speaker KV encode in full ({tenc:.2f}s), one 3-row CFG forward ({t3:.2f}s) and one 1-row forward ({t1:.2f}s) at S=640 "
                       f"x 20 steps each, DAC decode of {nf} of 640 frames ({tdac:.2f}s) x 10; estimated {est:.0f}s per utterance"}
@@ -211,6 +211,17 @@ def eager_gpu_baseline(state, pca, ids, tmask, spk, smask, sampler_kw, device):
             "ms_per_utterance": round(1e3 * tot, 1), "sampler_ms": round(times["sampler_ms"], 1), "dac_decode_ms": round(times["dac_ms"], 1),
             "finite": bool(torch.isfinite(wav).all()),
             "workload": f"one utterance per call, {sampler_kw['num_steps']} steps, bf16 EchoDiT + fp32 DAC, second of two runs"}
+
+
+def cpu_model() -> str:
+    """Model name of the host CPU the baseline ran on (/proc/cpuinfo)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def host_threads() -> int:
