@@ -49,7 +49,13 @@ namespace {
 template <int V> struct IC { static constexpr int value = V; };
 
 // lane id of this thread inside its wave, from the hardware (two VALU operations, no register carried from kernel entry)
-__device__ __forceinline__ int hw_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (the mask goes through an opaque asm: mbcnt is a pure function of constants to hipcc, which otherwise computes it once at kernel entry, keeps -
+// i.e. spills - the result and reloads it at every use behind a vmcnt(0))
+__device__ __forceinline__ int hw_lane() {
+  unsigned m = ~0u;
+  asm volatile("" : "+s"(m));
+  return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
+}
 
 
 __device__ __forceinline__ uint4 pack8_bf16(const float* y) {
