@@ -20,7 +20,11 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// s_waitcnt vmcnt(N) as the BUILTIN, not as inline asm: the compiler's wait-count pass then knows what has completed behind it.  As opaque asm it
+// did not, and where a spilled value was reloaded in front of the K loop (the fp8 QKV instantiation: the DMA offsets) it put its own vmcnt(0) in
+// front of the first use INSIDE the loop - every K-tile, draining the LDS-DMA ring this counted wait exists to keep full.
+// simm16 (gfx9): vmcnt[3:0] | expcnt[6:4] = 7 | lgkmcnt[11:8] = 15 | vmcnt[5:4] << 14
+template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
 
 template <typename T>
 __device__ __forceinline__ float vec_at(const void* p, long i) { return Num<T>::ld(((const T*)p)[i]); }

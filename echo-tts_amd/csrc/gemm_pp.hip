@@ -412,6 +412,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs p) {
   for (int v = blockIdx.x; v < ntiles; v += G) {
     int tile_m, tile_n;
     tile_of(v, tile_m, tile_n);
+    // the eight DMA offsets of the tile being staged are RECOMPUTED here (same values): they were last written in the previous tile's hand-over and
+    // nothing reads them during the epilogue, so hipcc spilled them there and reloaded them in front of the K loop - with the wait for that
+    // reload INSIDE the steady loop (fp8 QKV instantiation: a vmcnt(0) per K-tile, the LDS-DMA ring drained every time).  Redefined at the tile
+    // top, they are not live across the epilogue at all.
+    if constexpr (FP8 && TAIL == TAIL_QKV) set_stage_tile(v_stage);      // (this instantiation only: in the others the register allocation came out worse with it)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
