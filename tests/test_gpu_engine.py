@@ -6,6 +6,7 @@ fp32 engine against the fp32 reference.  The bf16 engine cannot meet 1e-3 agains
 run any more than PyTorch meets it against itself, so it is held to: no farther
 from the fp32 reference than 1.5x the reference's own bf16 run (+1e-3)."""
 import os
+import sys
 
 import pytest
 import torch
@@ -312,6 +313,35 @@ def test_dac_full_size_160_frames_against_oracle():
     e = rms(got, want)
     print(f"DAC full size, 160 frames: waveform rms error {e:.3e} (signal rms {U.rms(want):.3e})")
     assert got.shape == want.shape and e < WAV_TOL and e < 1e-3 * U.rms(want), (e, U.rms(want))
+
+
+def test_dac_conv_tails_equal_the_generic_tail_bit_for_bit(tmp_path):
+    """The branch-free conv tails of the tile kernels (gemm_epilogue NTAIL >= 2: clamped unconditional residual loads, idle threads' stores to
+    a sink, per-column operands in front of the pass loop) must compute exactly what the generic tail computes: a full-size decode of 160
+    frames with the conv tails on and off (ECHO_NT_CONV_TAILS, read once per process: two child processes), Snake on sinf() in both, must
+    give the same waveform bit for bit.  A third run with the default Snake (v_sin_f32) must stay within 1e-3 of the north-star tolerance of it."""
+    import subprocess
+    script = tmp_path / "decode.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import echo_tts_amd as E\n"
+        "from oracle import echo_ref as R\n"
+        "cfg = R.DacConfig(); w = R.make_dac_weights(cfg, 0)\n"
+        "z = torch.randn((1, cfg.latent_dim, 160), generator=torch.Generator().manual_seed(7))\n"
+        "dac = E.DAC(cfg, w, device='cuda:0')\n"
+        "torch.save(dac.decode_zq(z).cpu(), sys.argv[1])\n")
+    outs = {}
+    for name, env in (("conv", {"ECHO_NT_CONV_TAILS": "1", "ECHO_DAC_FAST_SIN": "0"}), ("generic", {"ECHO_NT_CONV_TAILS": "0", "ECHO_DAC_FAST_SIN": "0"}),
+                      ("default", {})):
+        out = tmp_path / f"{name}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = torch.load(out, weights_only=True)
+    assert torch.equal(outs["conv"], outs["generic"])
+    d = rms(outs["default"], outs["generic"])
+    print(f"DAC conv tails: bit-identical to the generic tail; v_sin_f32 Snake vs sinf: rms {d:.3e} (signal rms {U.rms(outs['generic']):.3e})")
+    assert d < 1e-3 * WAV_TOL
 
 
 @pytest.mark.parametrize("size, B, T", [("tiny", 3, 40), ("full", 5, 200)])
