@@ -3,6 +3,8 @@ called through the C ABI (echo_op_*).  bf16 kernels are compared with the fp32 r
 the reference's rounding points; fp32 kernels with an fp64 evaluation."""
 import ctypes as C
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -674,6 +676,52 @@ def test_gemm_pingpong_fused_qkv_tail_multi_tile(rows, S):
         if cfg == 5:
             assert torch.equal(out2[:, :3 * D], out[:, :3 * D]) and torch.equal(vt2, vt)
         U.bf16_close(out2[:, 3 * D:], torch.sigmoid(gte.float()).bfloat16(), ulps=1.0, frac_exact=0.995)
+
+
+def test_gemm_pingpong_tail_specialised_instantiations_equal_the_all_tails_build(tmp_path):
+    """The tail-specialised, branch-free instantiations of gemm_pp_kernel (plain / column scale + residual / fused QKV, interior and edge forms,
+    bf16 and fp8) against the one-kernel-with-every-tail instantiation (ECHO_PP_TAILS=0, read once per process: two child processes) on the
+    same seeded random operands: every output bit for bit - an interior-only shape and a ragged one (M = 5000, S = 200), in-place residual."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tails.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from tests import gpu_util as U\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "out = {}\n"
+        "D, K = 2048, 2048\n"
+        "for (B, S) in ((4, 640), (25, 200)):\n"
+        "    M = B * S\n"
+        "    A = (torch.rand((M + 256, K), generator=g) * 2 - 1).to(torch.bfloat16).cuda()\n"
+        "    W = ((torch.rand((4 * D, K), generator=g) * 2 - 1) * 0.05).to(torch.bfloat16).cuda()\n"
+        "    cs = torch.rand((D,), generator=g).to(torch.bfloat16).cuda()\n"
+        "    res = torch.randn((M, D), generator=g).to(torch.bfloat16).cuda()\n"
+        "    qk_w = (1 + 0.1 * torch.randn((2 * D,), generator=g)).to(torch.bfloat16).cuda()\n"
+        "    ang = torch.rand((S, 64), generator=g).cuda(); rope = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous()\n"
+        "    A8, sa = U.quant_rows_fp8(A); W8, sw = U.quant_rows_fp8(W)\n"
+        "    for name, a, w, extra in (('bf16', A, W, {}), ('fp8', A8, W8, dict(a_scale=sa, w_scale=sw))):\n"
+        "        c = torch.zeros((M, 4 * D), dtype=torch.bfloat16, device='cuda')\n"
+        "        U.gemm(a, w, c, M=M, N=4 * D, K=K, lda=K, ldw=K, ldc=4 * D, Npad=4 * D, cfg=5, **extra)\n"
+        "        out[f'plain_{name}_{M}'] = c.cpu()\n"
+        "        r = res.clone()\n"
+        "        U.gemm(a, w, r, M=M, N=D, K=K, lda=K, ldw=K, ldc=D, Npad=D, cfg=5, colscale=cs, res=r, ldres=D, **extra)\n"
+        "        out[f'csres_{name}_{M}'] = r.cpu()\n"
+        "        c = torch.zeros((M, 4 * D), dtype=torch.bfloat16, device='cuda'); vt = torch.zeros((B, D, S), dtype=torch.bfloat16, device='cuda')\n"
+        "        U.gemm(a, w, c, M=M, N=4 * D, K=K, lda=K, ldw=K, ldc=4 * D, Npad=4 * D, cfg=5, **extra,\n"
+        "               qkv=dict(D=D, S=S, rope_heads=8, pos0=0, eps=1e-6, qk_w=qk_w, rope=rope, vt=vt, vt_ld=S, vt_row_stride=D * S, gate_act=1))\n"
+        "        out[f'qkv_{name}_{M}'] = c.cpu(); out[f'vt_{name}_{M}'] = vt.cpu()\n"
+        "torch.cuda.synchronize(); torch.save(out, sys.argv[1])\n")
+    outs = {}
+    for tails in ("1", "0"):
+        o = tmp_path / f"tails{tails}.pt"
+        r = subprocess.run([sys.executable, str(script), str(o)], env=dict(os.environ, ECHO_PP_TAILS=tails), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tails] = torch.load(o, weights_only=True)
+    assert outs["1"].keys() == outs["0"].keys() and len(outs["1"]) == 16
+    for k in outs["1"]:
+        assert torch.equal(outs["1"][k], outs["0"][k]), k
 
 
 @pytest.mark.parametrize("B,S", [(24, 640), (5, 200), (7, 100), (3, 37)])
